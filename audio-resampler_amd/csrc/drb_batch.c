@@ -1,0 +1,628 @@
+/*
+ * The batched many-stream entry point: host scheduler + per-stream state.
+ *
+ * Per stream the host keeps what the upstream converter keeps in its passes
+ * that is not sample data - the fractional stage's accumulator and the
+ * slicer's fill level (drb-audio-converter.c:1494-1505, 2476-2484) - and the
+ * device keeps the sample data: the last `history` source frames, which is
+ * everything the filters still need from the past.  A step computes, on the
+ * host, how many frames every stream consumes and produces (closed forms,
+ * drb_plan.c), sends one small descriptor per stream to the device and
+ * launches two kernels: the cascade and the history update.
+ */
+#include "drb_audio_converter_amd.h"
+#include "drb_hip.h"
+#include "drb_plan.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+enum { ring_slots = 4, max_step_frames = 1 << 24 };
+
+struct DrbAmd_Batch
+{
+    DrbAmd_Batch_Config config;
+    Drb_Plan plan;
+    Drb_Geometry geometry;
+    Drb_Device_Chain chain;
+    int device;
+    int sample_bytes;
+
+    Drb_Stream_State * states;        /* host, one per stream                  */
+    Drb_Stream_State * trial_states;  /* host scratch for two-phase commit     */
+    Drb_Step * steps;                 /* host scratch                          */
+    void const ** dense_source;       /* host scratch for the dense entry      */
+    void ** dense_target;
+    int * dense_frames;
+    int * dense_capacity;
+    int * dense_produced;
+
+    float * history [2];              /* device, [stream][channel][history]    */
+    int history_current;
+
+    Drb_Device_Call * calls_device;
+    Drb_Device_Call * calls_host [ring_slots]; /* pinned                       */
+    void * slot_done [ring_slots];             /* events                       */
+    int slot_pending [ring_slots];
+    int slot;
+
+    int * fault_device;
+    int * fault_host;                 /* pinned                                */
+
+    int timing;                       /* bracket the cascade kernel with events */
+    void * kernel_start, * kernel_stop;
+    int kernel_timed;
+};
+
+/* ---- errors ---------------------------------------------------------------- */
+
+static _Thread_local char last_error [256];
+
+static DrbAmd_Status fail (DrbAmd_Status status, char const * format, ...)
+{
+    va_list arguments;
+    va_start(arguments, format);
+    vsnprintf(last_error, sizeof(last_error), format, arguments);
+    va_end(arguments);
+    return status;
+}
+
+static DrbAmd_Status fail_hip (char const * what, int code)
+{
+    return fail(drb_amd_error_device, "%s: %s", what, drb_hip_error_text(code));
+}
+
+char const * drb_amd_last_error (void) { return last_error; }
+
+/* ---- plan -> device chain --------------------------------------------------- */
+
+static int table_offset (int kind, int arg)
+{
+    /* float offsets into data/drb_tables.bin */
+    if (kind == drb_stage_sinc)
+    {
+        switch (arg)
+        {
+          case 16: return 168;
+          case 32: return 1192;
+          case 116: return 3240;
+          default: return 3752;
+        }
+    }
+
+    switch (arg)
+    {
+      case 16: return 0;
+      case 32: return 8;
+      case 48: return 24;
+      case 64: return 48;
+      case 80: return 80;
+      default: return 120;
+    }
+}
+
+static void build_chain (DrbAmd_Batch_Config const * config, Drb_Plan const * plan,
+                         Drb_Geometry const * geometry, Drb_Device_Chain * chain)
+{
+    memset(chain, 0, sizeof(*chain));
+
+    chain->channels = plan->channels;
+    chain->sinc_pull = plan->direction == 1;
+    chain->delay_edge = -1;
+    chain->history = geometry->history_frames;
+    chain->tile_frames = geometry->tile_frames;
+    chain->lds_width = geometry->lds_width;
+    chain->sample_type = config->sample_type;
+    chain->layout = config->layout;
+    chain->source_delta = plan->source_delta > 0 ? plan->source_delta : 1;
+    chain->target_delta = plan->target_delta > 0 ? plan->target_delta : 1;
+    chain->scale = 1.0 / (double)chain->source_delta; /* drb-audio-converter.c:1767 */
+
+    for (int k = 0; k < plan->stage_count; k++)
+    {
+        Drb_Stage const * const stage = &plan->stages[k];
+
+        if (stage->kind == drb_stage_delay)
+        {
+            chain->delay_edge = chain->stage_count;
+            continue;
+        }
+
+        Drb_Device_Stage * const out = &chain->stages[chain->stage_count++];
+
+        out->kind = stage->kind;
+        out->taps = stage->kind == drb_stage_sinc ? stage->arg % 100 : stage->arg / 2;
+        out->cubic = stage->kind == drb_stage_sinc && stage->arg >= 100;
+        out->table = table_offset(stage->kind, stage->arg);
+    }
+}
+
+static DrbAmd_Status resolve (DrbAmd_Batch_Config const * config, Drb_Plan * plan)
+{
+    int const status = drb_plan_resolve
+    (
+        config->source_sampling_rate, config->target_sampling_rate, config->channel_count,
+        config->block_size, config->max_block_count, config->direction, config->quality, plan
+    );
+
+    if (status == 0) return fail(drb_amd_error_invalid_conversion, "conversion rejected by validation");
+    if (status < 0) return fail(drb_amd_error_unsupported, "conversion needs more 2x stages than the filter tables hold");
+    if (!plan->runnable)
+    {
+        return fail(drb_amd_error_unsupported,
+                    plan->throttling == 0 ? "max_block_count leaves no room for a single sub-block"
+                                          : "a 2x stage would see odd frame counts (block_size 1 without a slicer)");
+    }
+    if ((unsigned)config->sample_type > drb_amd_sample_i32) return fail(drb_amd_error_bad_argument, "unknown sample type");
+    if ((unsigned)config->layout > drb_amd_layout_interleaved) return fail(drb_amd_error_bad_argument, "unknown layout");
+    if ((unsigned)config->arithmetic > drb_amd_arithmetic_fast) return fail(drb_amd_error_bad_argument, "unknown arithmetic mode");
+
+    return drb_amd_ok;
+}
+
+enum { lds_budget = 56 * 1024 };
+
+DrbAmd_Status drb_amd_plan_info (DrbAmd_Batch_Config const * config, DrbAmd_Plan_Info * info)
+{
+    Drb_Plan plan;
+    Drb_Geometry geometry;
+
+    if (!config || !info) return fail(drb_amd_error_bad_argument, "null argument");
+
+    DrbAmd_Status const status = resolve(config, &plan);
+
+    if (status != drb_amd_ok) return status;
+
+    drb_plan_geometry(&plan, lds_budget, &geometry);
+
+    memset(info, 0, sizeof(*info));
+
+    info->stage_count = plan.stage_count;
+
+    for (int k = 0; k < plan.stage_count; k++)
+    {
+        info->stage_kind[k] = plan.stages[k].kind;
+        info->stage_arg[k] = plan.stages[k].arg;
+    }
+
+    int const sample_bytes = config->sample_type == drb_amd_sample_i16 ? 2 : 4;
+
+    info->throttling = plan.throttling;
+    info->buffer_length = plan.buffer_length;
+    info->converter_size = plan.converter_size;
+    info->history_frames = geometry.history_frames;
+    info->tile_frames = geometry.tile_frames;
+    info->flops_per_output_sample = 2.0 * plan.macs_per_output_sample;
+    info->bytes_per_output_sample =
+        sample_bytes * ((double)plan.source_rate / plan.target_rate) + sample_bytes;
+
+    return drb_amd_ok;
+}
+
+int drb_amd_plan_describe
+    (
+        DrbAmd_Batch_Config const * config,
+        int passes [20], int edges [55], int * throttling, long * buffer_length
+    )
+{
+    Drb_Plan plan;
+
+    if (!config || drb_plan_resolve(config->source_sampling_rate, config->target_sampling_rate,
+                                    config->channel_count, config->block_size, config->max_block_count,
+                                    config->direction, config->quality, &plan) != 1)
+    {
+        return -1;
+    }
+
+    for (int i = 0; i < plan.pass_count; i++)
+    {
+        passes[2 * i] = plan.passes[i].kind;
+        passes[2 * i + 1] = plan.passes[i].arg;
+    }
+
+    for (int i = 0; i <= plan.pass_count; i++)
+    {
+        edges[5 * i + 0] = plan.edges[i].rate;
+        edges[5 * i + 1] = plan.edges[i].channels;
+        edges[5 * i + 2] = plan.edges[i].layout;
+        edges[5 * i + 3] = plan.edges[i].block;
+        edges[5 * i + 4] = plan.edges[i].max_blocks;
+    }
+
+    *throttling = plan.throttling;
+    *buffer_length = plan.buffer_length;
+
+    return plan.pass_count;
+}
+
+/* ---- create / destroy ------------------------------------------------------- */
+
+static void release (DrbAmd_Batch * batch)
+{
+    if (!batch) return;
+
+    for (int i = 0; i < ring_slots; i++)
+    {
+        if (batch->slot_done[i])
+        {
+            if (batch->slot_pending[i]) drb_hip_event_synchronize(batch->slot_done[i]);
+            drb_hip_event_destroy(batch->slot_done[i]);
+        }
+        if (batch->calls_host[i]) drb_hip_host_free(batch->calls_host[i]);
+    }
+
+    if (batch->kernel_start) drb_hip_event_destroy(batch->kernel_start);
+    if (batch->kernel_stop) drb_hip_event_destroy(batch->kernel_stop);
+    if (batch->history[0]) drb_hip_free(batch->history[0]);
+    if (batch->history[1]) drb_hip_free(batch->history[1]);
+    if (batch->calls_device) drb_hip_free(batch->calls_device);
+    if (batch->fault_device) drb_hip_free(batch->fault_device);
+    if (batch->fault_host) drb_hip_host_free(batch->fault_host);
+
+    free(batch->states);
+    free(batch->trial_states);
+    free(batch->steps);
+    free(batch->dense_source);
+    free(batch->dense_target);
+    free(batch->dense_frames);
+    free(batch->dense_capacity);
+    free(batch->dense_produced);
+    free(batch);
+}
+
+DrbAmd_Status drb_amd_batch_create (DrbAmd_Batch_Config const * config, DrbAmd_Batch ** out)
+{
+    if (!config || !out) return fail(drb_amd_error_bad_argument, "null argument");
+
+    *out = 0;
+
+    if (config->stream_count < 1) return fail(drb_amd_error_bad_argument, "stream_count must be positive");
+
+    Drb_Plan plan;
+    DrbAmd_Status status = resolve(config, &plan);
+
+    if (status != drb_amd_ok) return status;
+
+    /* the device: fail loudly, there is no host fallback */
+    int device_count = 0, device = config->device, is_gfx950 = 0, lds_per_block = 0, code;
+
+    if ((code = drb_hip_device_count(&device_count)) != 0 || device_count < 1)
+    {
+        return fail(drb_amd_error_no_device, "no HIP device visible (%s)", code ? drb_hip_error_text(code) : "count is 0");
+    }
+
+    if (device < 0 && (code = drb_hip_get_device(&device)) != 0) return fail_hip("hipGetDevice", code);
+    if (device >= device_count) return fail(drb_amd_error_no_device, "device %d of %d does not exist", device, device_count);
+    if ((code = drb_hip_device_is_gfx950(device, &is_gfx950, &lds_per_block)) != 0) return fail_hip("hipGetDeviceProperties", code);
+    if (!is_gfx950) return fail(drb_amd_error_no_device, "device %d is not gfx950; this library carries gfx950 code only", device);
+    if ((code = drb_hip_set_device(device)) != 0) return fail_hip("hipSetDevice", code);
+
+    DrbAmd_Batch * const batch = calloc(1, sizeof(*batch));
+
+    if (!batch) return fail(drb_amd_error_out_of_memory, "out of host memory");
+
+    batch->config = *config;
+    batch->plan = plan;
+    batch->device = device;
+    batch->sample_bytes = config->sample_type == drb_amd_sample_i16 ? 2 : 4;
+
+    drb_plan_geometry(&plan, lds_budget, &batch->geometry);
+    build_chain(config, &plan, &batch->geometry, &batch->chain);
+
+    size_t const n = (size_t)config->stream_count;
+
+    batch->states = calloc(n, sizeof(Drb_Stream_State));
+    batch->trial_states = calloc(n, sizeof(Drb_Stream_State));
+    batch->steps = calloc(n, sizeof(Drb_Step));
+    batch->dense_source = calloc(n, sizeof(void *));
+    batch->dense_target = calloc(n, sizeof(void *));
+    batch->dense_frames = calloc(n, sizeof(int));
+    batch->dense_capacity = calloc(n, sizeof(int));
+    batch->dense_produced = calloc(n, sizeof(int));
+
+    if (!batch->states || !batch->trial_states || !batch->steps || !batch->dense_source
+        || !batch->dense_target || !batch->dense_frames || !batch->dense_capacity || !batch->dense_produced)
+    {
+        release(batch);
+        return fail(drb_amd_error_out_of_memory, "out of host memory");
+    }
+
+    size_t const history_bytes = n * plan.channels * batch->geometry.history_frames * sizeof(float);
+
+    code = drb_hip_alloc((void **)&batch->history[0], history_bytes);
+    if (!code) code = drb_hip_alloc((void **)&batch->history[1], history_bytes);
+    if (!code) code = drb_hip_alloc((void **)&batch->calls_device, n * sizeof(Drb_Device_Call));
+    if (!code) code = drb_hip_alloc((void **)&batch->fault_device, sizeof(int));
+    if (!code) code = drb_hip_host_alloc((void **)&batch->fault_host, sizeof(int));
+
+    for (int i = 0; i < ring_slots && !code; i++)
+    {
+        code = drb_hip_host_alloc((void **)&batch->calls_host[i], n * sizeof(Drb_Device_Call));
+        if (!code) code = drb_hip_event_create(&batch->slot_done[i]);
+    }
+
+    if (!code) code = drb_hip_memset_async(batch->fault_device, 0, sizeof(int), 0);
+
+    if (code)
+    {
+        release(batch);
+        return fail(drb_amd_error_out_of_memory, "device allocation failed: %s", drb_hip_error_text(code));
+    }
+
+    *batch->fault_host = 0;
+
+    status = drb_amd_batch_reset(batch, 0, config->stream_count);
+
+    if (status != drb_amd_ok)
+    {
+        release(batch);
+        return status;
+    }
+
+    *out = batch;
+
+    return drb_amd_ok;
+}
+
+void drb_amd_batch_destroy (DrbAmd_Batch * batch)
+{
+    if (!batch) return;
+
+    drb_hip_set_device(batch->device);
+    release(batch);
+}
+
+DrbAmd_Status drb_amd_batch_reset (DrbAmd_Batch * batch, int first, int count)
+{
+    if (!batch || first < 0 || count < 0 || first + count > batch->config.stream_count)
+    {
+        return fail(drb_amd_error_bad_argument, "bad stream range");
+    }
+
+    int code = drb_hip_set_device(batch->device);
+
+    /* earlier steps may still be reading the history */
+    for (int i = 0; i < ring_slots && !code; i++)
+    {
+        if (batch->slot_pending[i])
+        {
+            code = drb_hip_event_synchronize(batch->slot_done[i]);
+            batch->slot_pending[i] = 0;
+        }
+    }
+
+    size_t const per_stream = (size_t)batch->plan.channels * batch->geometry.history_frames * sizeof(float);
+
+    for (int i = 0; i < 2 && !code; i++)
+    {
+        code = drb_hip_memset_async((char *)batch->history[i] + first * per_stream, 0, count * per_stream, 0);
+    }
+
+    if (!code) code = drb_hip_stream_synchronize(0);
+    if (code) return fail_hip("history reset", code);
+
+    for (int s = first; s < first + count; s++) drb_stream_reset(&batch->plan, &batch->states[s]);
+
+    return drb_amd_ok;
+}
+
+/* ---- stepping ---------------------------------------------------------------- */
+
+DrbAmd_Status drb_amd_batch_query (DrbAmd_Batch const * batch, int const * frames, int * counts)
+{
+    if (!batch || !frames || !counts) return fail(drb_amd_error_bad_argument, "null argument");
+
+    int const pull = batch->plan.direction == 1;
+
+    for (int s = 0; s < batch->config.stream_count; s++)
+    {
+        Drb_Stream_State state = batch->states[s];
+        Drb_Step step;
+
+        if (frames[s] < 0 || frames[s] > max_step_frames) return fail(drb_amd_error_bad_argument, "stream %d: frame count %d out of range", s, frames[s]);
+        if (!drb_stream_step(&batch->plan, &state, frames[s], &step)) return fail(drb_amd_error_bad_argument, "stream %d: odd frame count reaches a 2x stage", s);
+
+        counts[s] = pull ? step.source_frames : step.target_frames;
+    }
+
+    return drb_amd_ok;
+}
+
+DrbAmd_Status drb_amd_batch_process
+    (
+        DrbAmd_Batch * batch,
+        void const * const * source, long long source_channel_stride,
+        int const * source_frames,
+        void * const * target, long long target_channel_stride,
+        int const * target_frames,
+        int * produced,
+        void * hip_stream
+    )
+{
+    if (!batch || !source || !source_frames || !target || !target_frames)
+    {
+        return fail(drb_amd_error_bad_argument, "null argument");
+    }
+
+    int const n = batch->config.stream_count;
+    int const pull = batch->plan.direction == 1;
+    int most_target = 0, code;
+
+    /* phase 1: frame arithmetic on a copy of the state, so that a rejected
+     * call leaves the batch untouched */
+    for (int s = 0; s < n; s++)
+    {
+        int const frames = pull ? target_frames[s] : source_frames[s];
+        Drb_Step * const step = &batch->steps[s];
+
+        batch->trial_states[s] = batch->states[s];
+
+        if (frames < 0 || frames > max_step_frames) return fail(drb_amd_error_bad_argument, "stream %d: frame count %d out of range", s, frames);
+        if (!drb_stream_step(&batch->plan, &batch->trial_states[s], frames, step)) return fail(drb_amd_error_bad_argument, "stream %d: odd frame count reaches a 2x stage", s);
+
+        if (pull && step->source_frames > source_frames[s]) return fail(drb_amd_error_capacity, "stream %d: %d source frames needed, %d supplied", s, step->source_frames, source_frames[s]);
+        if (!pull && step->target_frames > target_frames[s]) return fail(drb_amd_error_capacity, "stream %d: %d target frames produced, room for %d", s, step->target_frames, target_frames[s]);
+        if ((step->source_frames > 0 && !source[s]) || (step->target_frames > 0 && !target[s])) return fail(drb_amd_error_bad_argument, "stream %d: null buffer", s);
+
+        if (step->target_frames > most_target) most_target = step->target_frames;
+    }
+
+    if ((code = drb_hip_set_device(batch->device)) != 0) return fail_hip("hipSetDevice", code);
+
+    /* phase 2: descriptors -> device, launch */
+    int const slot = batch->slot;
+
+    if (batch->slot_pending[slot])
+    {
+        if ((code = drb_hip_event_synchronize(batch->slot_done[slot])) != 0) return fail_hip("hipEventSynchronize", code);
+        batch->slot_pending[slot] = 0;
+
+        if (*batch->fault_host) return fail(drb_amd_error_device, "kernel range check failed (code %d)", *batch->fault_host);
+    }
+
+    Drb_Device_Call * const calls = batch->calls_host[slot];
+
+    for (int s = 0; s < n; s++)
+    {
+        Drb_Step const * const step = &batch->steps[s];
+
+        calls[s].source = (unsigned long long)(size_t)source[s];
+        calls[s].target = (unsigned long long)(size_t)target[s];
+        calls[s].phase = step->phase;
+        calls[s].source_frames = step->source_frames;
+        calls[s].target_frames = step->target_frames;
+        calls[s].delay = step->delay;
+        calls[s].reserved = 0;
+    }
+
+    float * const history_in = batch->history[batch->history_current];
+    float * const history_out = batch->history[batch->history_current ^ 1];
+    int const tile = batch->geometry.tile_frames;
+
+    code = drb_hip_upload_async(batch->calls_device, calls, (size_t)n * sizeof(Drb_Device_Call), hip_stream);
+
+    if (!code && batch->timing) code = drb_hip_event_record(batch->kernel_start, hip_stream);
+
+    if (!code)
+    {
+        code = drb_hip_launch_cascade
+        (
+            &batch->chain, batch->config.arithmetic == drb_amd_arithmetic_exact,
+            batch->calls_device, n, (most_target + tile - 1) / tile, history_in,
+            source_channel_stride, target_channel_stride,
+            batch->geometry.lds_bytes, batch->fault_device, hip_stream
+        );
+    }
+
+    if (!code && batch->timing)
+    {
+        code = drb_hip_event_record(batch->kernel_stop, hip_stream);
+        batch->kernel_timed = 1;
+    }
+
+    if (!code)
+    {
+        code = drb_hip_launch_history
+        (
+            &batch->chain, batch->calls_device, n, history_in, history_out,
+            source_channel_stride, hip_stream
+        );
+    }
+
+    if (!code) code = drb_hip_download_async(batch->fault_host, batch->fault_device, sizeof(int), hip_stream);
+    if (!code) code = drb_hip_event_record(batch->slot_done[slot], hip_stream);
+
+    if (code) return fail_hip("launch", code);
+
+    batch->slot_pending[slot] = 1;
+    batch->slot = (slot + 1) % ring_slots;
+    batch->history_current ^= 1;
+
+    for (int s = 0; s < n; s++)
+    {
+        batch->states[s] = batch->trial_states[s];
+        if (produced) produced[s] = pull ? batch->steps[s].source_frames : batch->steps[s].target_frames;
+    }
+
+    return drb_amd_ok;
+}
+
+DrbAmd_Status drb_amd_batch_process_dense
+    (
+        DrbAmd_Batch * batch,
+        void const * source_base, long long source_stream_stride, long long source_channel_stride,
+        void * target_base, long long target_stream_stride, long long target_channel_stride,
+        int frames, int capacity,
+        int * produced_each,
+        void * hip_stream
+    )
+{
+    if (!batch) return fail(drb_amd_error_bad_argument, "null argument");
+
+    int const n = batch->config.stream_count;
+    int const pull = batch->plan.direction == 1;
+
+    for (int s = 0; s < n; s++)
+    {
+        batch->dense_source[s] = (char const *)source_base + (long long)s * source_stream_stride * batch->sample_bytes;
+        batch->dense_target[s] = (char *)target_base + (long long)s * target_stream_stride * batch->sample_bytes;
+        batch->dense_frames[s] = frames;
+        batch->dense_capacity[s] = capacity;
+    }
+
+    return drb_amd_batch_process
+    (
+        batch,
+        batch->dense_source, source_channel_stride, pull ? batch->dense_capacity : batch->dense_frames,
+        batch->dense_target, target_channel_stride, pull ? batch->dense_frames : batch->dense_capacity,
+        produced_each ? produced_each : batch->dense_produced, hip_stream
+    );
+}
+
+DrbAmd_Status drb_amd_batch_synchronize (DrbAmd_Batch * batch, void * hip_stream)
+{
+    if (!batch) return fail(drb_amd_error_bad_argument, "null argument");
+
+    int code = drb_hip_set_device(batch->device);
+
+    if (!code) code = drb_hip_stream_synchronize(hip_stream);
+    if (code) return fail_hip("hipStreamSynchronize", code);
+
+    if (*batch->fault_host) return fail(drb_amd_error_device, "kernel range check failed (code %d)", *batch->fault_host);
+
+    return drb_amd_ok;
+}
+
+DrbAmd_Status drb_amd_batch_time_kernels (DrbAmd_Batch * batch, int enable)
+{
+    if (!batch) return fail(drb_amd_error_bad_argument, "null argument");
+
+    if (enable && !batch->kernel_start)
+    {
+        int code = drb_hip_set_device(batch->device);
+
+        if (!code) code = drb_hip_timing_event_create(&batch->kernel_start);
+        if (!code) code = drb_hip_timing_event_create(&batch->kernel_stop);
+        if (code) return fail_hip("hipEventCreate", code);
+    }
+
+    batch->timing = enable != 0;
+    batch->kernel_timed = 0;
+
+    return drb_amd_ok;
+}
+
+DrbAmd_Status drb_amd_batch_kernel_ms (DrbAmd_Batch * batch, float * milliseconds)
+{
+    if (!batch || !milliseconds) return fail(drb_amd_error_bad_argument, "null argument");
+    if (!batch->kernel_timed) return fail(drb_amd_error_bad_argument, "no timed kernel launch yet");
+
+    int code = drb_hip_event_synchronize(batch->kernel_stop);
+
+    if (!code) code = drb_hip_event_elapsed_ms(milliseconds, batch->kernel_start, batch->kernel_stop);
+    if (code) return fail_hip("hipEventElapsedTime", code);
+
+    return drb_amd_ok;
+}

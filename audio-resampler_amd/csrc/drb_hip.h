@@ -1,0 +1,102 @@
+/* The thin C ABI between the host code (plain C) and the HIP translation unit.
+ * Host files include only this header, never a HIP header. */
+#ifndef DRB_HIP_H
+#define DRB_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { drb_device_max_stages = 8 };
+
+typedef struct Drb_Device_Stage
+{
+    int kind;    /* drb_stage_up2x / drb_stage_down2x / drb_stage_sinc          */
+    int taps;    /* half-band: order / 2; fractional stage: 16 or 32            */
+    int table;   /* float offset of the coefficients in the table blob          */
+    int cubic;   /* fractional stage: 1 = four-row Catmull-Rom blend            */
+}
+Drb_Device_Stage;
+
+/* One conversion chain, passed to the kernels by value. */
+typedef struct Drb_Device_Chain
+{
+    int stage_count;         /* filtering stages only                            */
+    int channels;
+    int sinc_pull;           /* phase convention of the fractional stage         */
+    int delay_edge;          /* edge the slicer delay sits on (0 = in front of
+                                stage 0 ... stage_count = behind the last), -1   */
+    int history;             /* source frames of look-back kept per stream       */
+    int tile_frames;         /* target frames per workgroup                      */
+    int lds_width;           /* floats per channel per staging buffer            */
+    int sample_type;         /* DrbAmd_Sample_Type                               */
+    int layout;              /* DrbAmd_Layout                                    */
+    int reserved;
+    long long source_delta;  /* 2^48 / fractional stage input rate               */
+    long long target_delta;  /* 2^48 / fractional stage output rate              */
+    double scale;            /* 1.0 / source_delta                               */
+    Drb_Device_Stage stages [drb_device_max_stages];
+}
+Drb_Device_Chain;
+
+/* One stream's share of one step. */
+typedef struct Drb_Device_Call
+{
+    unsigned long long source;   /* device address of the chunk's first sample */
+    unsigned long long target;
+    long long phase;             /* accumulator at the start of the step       */
+    int source_frames;
+    int target_frames;
+    int delay;                   /* slicer delay in frames for this step       */
+    int reserved;
+}
+Drb_Device_Call;
+
+/* All functions return 0 on success, else a HIP error code. */
+int drb_hip_device_count (int * count);
+int drb_hip_get_device (int * device);
+int drb_hip_set_device (int device);
+int drb_hip_device_is_gfx950 (int device, int * yes, int * lds_bytes_per_block);
+int drb_hip_alloc (void ** pointer, size_t bytes);
+int drb_hip_free (void * pointer);
+int drb_hip_host_alloc (void ** pointer, size_t bytes);
+int drb_hip_host_free (void * pointer);
+int drb_hip_memset_async (void * pointer, int value, size_t bytes, void * stream);
+int drb_hip_upload_async (void * device, void const * host, size_t bytes, void * stream);
+int drb_hip_download_async (void * host, void const * device, size_t bytes, void * stream);
+int drb_hip_stream_synchronize (void * stream);
+int drb_hip_event_create (void ** event);
+int drb_hip_timing_event_create (void ** event);
+int drb_hip_event_elapsed_ms (float * ms, void * start, void * stop);
+int drb_hip_event_destroy (void * event);
+int drb_hip_event_record (void * event, void * stream);
+int drb_hip_event_synchronize (void * event);
+char const * drb_hip_error_text (int code);
+
+/* Filters one step of every stream: grid = stream_count x max_tiles. */
+int drb_hip_launch_cascade
+    (
+        Drb_Device_Chain const * chain, int exact,
+        Drb_Device_Call const * calls, int stream_count, int max_tiles,
+        float const * history,
+        long long source_channel_stride, long long target_channel_stride,
+        int lds_bytes, int * fault_flag, void * stream
+    );
+
+/* Writes every stream's new look-back (the last `history` source frames seen
+ * so far) into history_out. */
+int drb_hip_launch_history
+    (
+        Drb_Device_Chain const * chain,
+        Drb_Device_Call const * calls, int stream_count,
+        float const * history_in, float * history_out,
+        long long source_channel_stride, void * stream
+    );
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

@@ -1,0 +1,785 @@
+// gfx950 kernels for the resampling cascade, and the thin C ABI the host code
+// (plain C) uses to reach HIP.
+//
+// Execution model.  One workgroup produces one tile of `tile_frames` target
+// frames of one stream, all channels.  It first walks the chain backwards to
+// find which index range it needs on every edge between stages, then walks
+// forwards: load the source range (history + new chunk) into LDS, run every
+// stage LDS -> LDS, store the tile.  Nothing but the source chunk, the
+// per-stream history and the target tile touches HBM.  Stages are pure
+// functions of the frame index (zero input before the start of the stream),
+// so the halo a tile recomputes is bit-identical to what its neighbour
+// computes and a stream may be cut into tiles and steps anywhere.
+//
+// The "exact" arithmetic below reproduces the upstream scalar code path bit
+// for bit: float32 data, every product and every sum rounded separately, taps
+// accumulated in ascending order (drb-audio-converter.c:615-798).
+
+#include <hip/hip_runtime.h>
+
+#include "drb_hip.h"
+
+namespace
+{
+
+constexpr int kThreads = 256;
+
+enum { kStageUp2x = 1, kStageDown2x = 2, kStageSinc = 3 };
+enum { kSampleF32 = 0, kSampleI16 = 1, kSampleI32 = 2 };
+enum { kPlanar = 0, kInterleaved = 1 };
+
+// The coefficient tables (data/drb_tables.bin) as bit patterns.
+__constant__ unsigned int drb_table_words [] =
+{
+#include "../../data/drb_tables_words.inc"
+};
+
+__device__ inline float const * table_at (int float_offset)
+{
+    return reinterpret_cast<float const *>(drb_table_words) + float_offset;
+}
+
+// One rounding per operation, whatever the contraction flags say.
+__device__ inline float mul (float a, float b) { return __fmul_rn(a, b); }
+__device__ inline float add (float a, float b) { return __fadd_rn(a, b); }
+__device__ inline float mac (float acc, float a, float b) { return __fadd_rn(acc, __fmul_rn(a, b)); }
+
+__device__ inline int floor_half (int v) { return v >> 1; }
+
+// ---- sample load / store with type conversion ------------------------------
+
+__device__ inline float load_sample (void const * base, long long index, int type)
+{
+    switch (type)
+    {
+      case kSampleI16:
+        return static_cast<float>(static_cast<short const *>(base)[index]) * (1.0f / 32768.0f);
+      case kSampleI32:
+        return static_cast<float>(static_cast<int const *>(base)[index]) * (1.0f / 2147483648.0f);
+      default:
+        return static_cast<float const *>(base)[index];
+    }
+}
+
+__device__ inline void store_sample (void * base, long long index, int type, float value)
+{
+    switch (type)
+    {
+      case kSampleI16:
+      {
+        float const scaled = rintf(mul(value, 32768.0f));
+        int const q = scaled >= 32767.0f ? 32767
+                    : scaled <= -32768.0f ? -32768
+                    : scaled != scaled ? 0 : static_cast<int>(scaled);
+        static_cast<short *>(base)[index] = static_cast<short>(q);
+        break;
+      }
+      case kSampleI32:
+      {
+        float const scaled = rintf(mul(value, 2147483648.0f));
+        int const q = scaled >= 2147483648.0f ? 2147483647
+                    : scaled <= -2147483648.0f ? (-2147483647 - 1)
+                    : scaled != scaled ? 0 : static_cast<int>(scaled);
+        static_cast<int *>(base)[index] = q;
+        break;
+      }
+      default:
+        static_cast<float *>(base)[index] = value;
+    }
+}
+
+// Source frame `frame` of channel `channel` of one stream, where negative
+// frames come from the stream's history and frames before that are silence.
+__device__ inline float source_frame
+    (
+        Drb_Device_Chain const & chain, Drb_Device_Call const & call,
+        float const * history, long long channel_stride, int channel, int frame
+    )
+{
+    if (frame < 0)
+    {
+        return frame >= -chain.history ? history[channel * chain.history + chain.history + frame] : 0.0f;
+    }
+
+    if (frame >= call.source_frames) return 0.0f;
+
+    long long const index = chain.layout == kInterleaved
+        ? static_cast<long long>(frame) * chain.channels + channel
+        : channel * channel_stride + frame;
+
+    return load_sample(reinterpret_cast<void const *>(call.source), index, chain.sample_type);
+}
+
+// ---- fractional stage position ---------------------------------------------
+
+// For accumulator value `phase` (drb-audio-converter.c:1617-1648 push,
+// 1677-1707 pull): the number of source frames consumed before this output
+// (relative to the step) and the sub-sample position in [0, 1).
+//   push: m = ceil(phase / Sd) - 1, blend = (phase - m Sd - 1) / Sd
+//   pull: m = floor(phase / Sd),    blend = (phase - m Sd) / Sd
+__device__ inline void sinc_position
+    (
+        long long phase, long long sd, double scale, int pull, int & consumed, double & blend
+    )
+{
+    long long q = static_cast<long long>(floor(static_cast<double>(phase) * scale));
+    long long r = phase - q * sd;
+
+    while (r < 0) { q -= 1; r += sd; }
+    while (r >= sd) { q += 1; r -= sd; }
+
+    if (pull)
+    {
+        blend = static_cast<double>(r) * scale;
+    }
+    else
+    {
+        if (r == 0) { q -= 1; r = sd; }
+        blend = static_cast<double>(r - 1) * scale;
+    }
+
+    consumed = static_cast<int>(q);
+}
+
+// ---- edge buffers -----------------------------------------------------------
+
+// An edge buffer holds, per channel, `width` floats.  Position 0 is the lowest
+// index the consumer of the edge reads.  A decimator reads every other sample,
+// so the edge in front of one is stored as two planes (even positions, then
+// odd positions) to keep its reads contiguous.
+__device__ inline void put (float * channel_base, int width, int split, int position, float value)
+{
+    if (position < 0 || position >= width) return;
+
+    int const at = split ? (position & 1) * (width >> 1) + (position >> 1) : position;
+
+    channel_base[at] = value;
+}
+
+struct Ranges
+{
+    int lo [drb_device_max_stages + 1];  // consumer index stored at position 0, per edge
+    int hi [drb_device_max_stages + 1];
+    int fault;
+};
+
+// ---- half-band 2x up-sampler -----------------------------------------------
+// y[2f] = (x[f - N/2] * 0.5) * 2 ; y[2f+1] = 2 * sum_j k[j] x[f - N + 1 + j]
+// (drb-audio-converter.c:1984-2004).  Position 0 of the input edge is
+// x[first_frame - N + 1].  Each work item produces four consecutive source
+// frames' worth of output for one channel from one aligned window in registers.
+template <int N>
+__device__ void stage_up2x
+    (
+        float const * in, float * out, int width, int channels, int out_split,
+        int frames, int out_offset, float const * kernel
+    )
+{
+    int const groups = (frames + 3) >> 2;
+
+    for (int item = threadIdx.x; item < groups * channels; item += kThreads)
+    {
+        int const channel = item / groups, group = item - channel * groups;
+        float const * const src = in + channel * width + 4 * group;
+
+        float window [N + 4];
+
+        #pragma unroll
+        for (int chunk = 0; chunk < N / 4 + 1; chunk++)
+        {
+            float4 const v = *reinterpret_cast<float4 const *>(src + 4 * chunk);
+            window[4 * chunk + 0] = v.x;
+            window[4 * chunk + 1] = v.y;
+            window[4 * chunk + 2] = v.z;
+            window[4 * chunk + 3] = v.w;
+        }
+
+        float * const dst = out + channel * width;
+
+        #pragma unroll
+        for (int r = 0; r < 4; r++)
+        {
+            float acc = 0.0f;
+
+            #pragma unroll
+            for (int j = 0; j < N; j++) acc = mac(acc, kernel[j], window[r + j]);
+
+            float const even = mul(mul(window[r + N / 2 - 1], 0.5f), 2.0f);
+            float const odd = mul(acc, 2.0f);
+
+            if (4 * group + r < frames)
+            {
+                int const position = 2 * (4 * group + r) + out_offset;
+                put(dst, width, out_split, position, even);
+                put(dst, width, out_split, position + 1, odd);
+            }
+        }
+    }
+}
+
+// ---- half-band 2x down-sampler ---------------------------------------------
+// y[f] = 0.5 x[2f - N] + sum_j k[j] x[2 (f - N + j) + 1]
+// (drb-audio-converter.c:2033-2057).  Position 0 of the (two-plane) input edge
+// is x[2 first_frame - 2N + 1]; the taps therefore sit in plane 0 and the
+// centre sample in plane 1.
+template <int N>
+__device__ void stage_down2x
+    (
+        float const * in, float * out, int width, int channels, int out_split,
+        int frames, float const * kernel
+    )
+{
+    int const groups = (frames + 3) >> 2;
+    int const plane = width >> 1;
+    constexpr int kCentre = N / 2 - 1;
+
+    for (int item = threadIdx.x; item < groups * channels; item += kThreads)
+    {
+        int const channel = item / groups, group = item - channel * groups;
+        float const * const taps = in + channel * width + 4 * group;
+        float const * const centre = in + channel * width + plane + 4 * group + (kCentre & ~3);
+
+        float window [N + 4];
+        float middle [8];
+
+        #pragma unroll
+        for (int chunk = 0; chunk < N / 4 + 1; chunk++)
+        {
+            float4 const v = *reinterpret_cast<float4 const *>(taps + 4 * chunk);
+            window[4 * chunk + 0] = v.x;
+            window[4 * chunk + 1] = v.y;
+            window[4 * chunk + 2] = v.z;
+            window[4 * chunk + 3] = v.w;
+        }
+
+        #pragma unroll
+        for (int chunk = 0; chunk < 2; chunk++)
+        {
+            float4 const v = *reinterpret_cast<float4 const *>(centre + 4 * chunk);
+            middle[4 * chunk + 0] = v.x;
+            middle[4 * chunk + 1] = v.y;
+            middle[4 * chunk + 2] = v.z;
+            middle[4 * chunk + 3] = v.w;
+        }
+
+        float * const dst = out + channel * width;
+
+        #pragma unroll
+        for (int r = 0; r < 4; r++)
+        {
+            float acc = 0.0f;
+
+            #pragma unroll
+            for (int j = 0; j < N; j++) acc = mac(acc, kernel[j], window[r + j]);
+
+            float const value = add(mul(middle[r + (kCentre & 3)], 0.5f), acc);
+
+            if (4 * group + r < frames) put(dst, width, out_split, 4 * group + r, value);
+        }
+    }
+}
+
+// ---- windowed-sinc fractional stage -----------------------------------------
+// One work item = one output frame, all channels two at a time.  The bank rows
+// (64 x TAPS linear, 32 x TAPS cubic) sit in LDS with a one-float skew per row
+// so that lanes reading different rows at the same tap hit different banks.
+// Row pick and blend: drb-audio-converter.c:881-941; linear blend 827-848;
+// Catmull-Rom 850-875.
+template <int TAPS, int CUBIC>
+__device__ void stage_sinc
+    (
+        Drb_Device_Chain const & chain, long long phase_base,
+        float const * in, float * out, int width, int channels, int out_split,
+        int first_output, int outputs, int in_origin, float const * bank
+    )
+{
+    constexpr int kRows = CUBIC ? 4 : 2;
+    constexpr int kStride = TAPS + 1;
+    double const bank_scale = CUBIC ? 29.0 : 63.0;
+
+    for (int item = threadIdx.x; item < outputs; item += kThreads)
+    {
+        int consumed;
+        double blend;
+
+        sinc_position
+        (
+            phase_base + static_cast<long long>(first_output + item) * chain.target_delta,
+            chain.source_delta, chain.scale, chain.sinc_pull, consumed, blend
+        );
+
+        double const scaled = blend * bank_scale;
+        int const row = static_cast<int>(scaled);
+        float const sub = static_cast<float>(scaled - static_cast<double>(row));
+
+        float const * const rows = bank + row * kStride;
+        int const start = consumed - TAPS - in_origin;
+
+        for (int channel = 0; channel < channels; channel += 2)
+        {
+            bool const pair = channel + 1 < channels;
+            float const * const a = in + channel * width + start;
+            float const * const b = pair ? a + width : a;
+
+            float pa [kRows], pb [kRows];
+
+            #pragma unroll
+            for (int r = 0; r < kRows; r++) { pa[r] = 0.0f; pb[r] = 0.0f; }
+
+            #pragma unroll
+            for (int t = 0; t < TAPS; t++)
+            {
+                float const xa = a[t], xb = b[t];
+
+                #pragma unroll
+                for (int r = 0; r < kRows; r++)
+                {
+                    float const k = rows[r * kStride + t];
+                    pa[r] = mac(pa[r], k, xa);
+                    pb[r] = mac(pb[r], k, xb);
+                }
+            }
+
+            float ya, yb;
+
+            if (CUBIC)
+            {
+                // a_i = sum_j M[i][j] p[j], accumulated from zero in order
+                float const m [4][4] =
+                {
+                    {  0.0f,  1.0f,  0.0f,  0.0f },
+                    { -0.5f,  0.0f,  0.5f,  0.0f },
+                    {  1.0f, -2.5f,  2.0f, -0.5f },
+                    { -0.5f,  1.5f, -1.5f,  0.5f }
+                };
+                float ca [4], cb [4];
+
+                #pragma unroll
+                for (int i = 0; i < 4; i++)
+                {
+                    float sa = 0.0f, sb = 0.0f;
+
+                    #pragma unroll
+                    for (int j = 0; j < 4; j++)
+                    {
+                        sa = mac(sa, m[i][j], pa[j]);
+                        sb = mac(sb, m[i][j], pb[j]);
+                    }
+
+                    ca[i] = sa;
+                    cb[i] = sb;
+                }
+
+                ya = add(mul(add(mul(add(mul(ca[3], sub), ca[2]), sub), ca[1]), sub), ca[0]);
+                yb = add(mul(add(mul(add(mul(cb[3], sub), cb[2]), sub), cb[1]), sub), cb[0]);
+            }
+            else
+            {
+                float const a0 = mac(mac(0.0f, 1.0f, pa[0]), 0.0f, pa[1]);
+                float const a1 = mac(mac(0.0f, -1.0f, pa[0]), 1.0f, pa[1]);
+                float const b0 = mac(mac(0.0f, 1.0f, pb[0]), 0.0f, pb[1]);
+                float const b1 = mac(mac(0.0f, -1.0f, pb[0]), 1.0f, pb[1]);
+
+                ya = add(mul(a1, sub), a0);
+                yb = add(mul(b1, sub), b0);
+            }
+
+            put(out + channel * width, width, out_split, item, ya);
+            if (pair) put(out + (channel + 1) * width, width, out_split, item, yb);
+        }
+    }
+}
+
+template <int N>
+__device__ inline void run_half_band
+    (
+        int kind, float const * in, float * out, int width, int channels, int out_split,
+        int frames, int out_offset, float const * kernel
+    )
+{
+    if (kind == kStageUp2x) stage_up2x<N>(in, out, width, channels, out_split, frames, out_offset, kernel);
+    else stage_down2x<N>(in, out, width, channels, out_split, frames, kernel);
+}
+
+// ---- the cascade kernel -----------------------------------------------------
+
+__global__ __launch_bounds__(kThreads) void drb_cascade_kernel
+    (
+        Drb_Device_Chain const chain,
+        Drb_Device_Call const * __restrict__ calls, int stream_count,
+        float const * __restrict__ history,
+        long long source_channel_stride, long long target_channel_stride,
+        int bank_floats, int * fault_flag
+    )
+{
+    // All LDS is one dynamic array (staging buffers, coefficient bank, ranges):
+    // a static __shared__ object in front of it would misalign the float4 reads.
+    extern __shared__ __attribute__((aligned(16))) float lds [];
+
+    int const stream = blockIdx.x % stream_count;
+    int const tile = blockIdx.x / stream_count;
+    Drb_Device_Call const call = calls[stream];
+
+    int const first = tile * chain.tile_frames;
+
+    if (first >= call.target_frames) return;
+
+    int const last = min(first + chain.tile_frames, call.target_frames);
+    int const stages = chain.stage_count;
+    int const width = chain.lds_width;
+    int const channels = chain.channels;
+
+    float * const buffers [2] = { lds, lds + channels * width };
+    float * const bank = lds + 2 * channels * width;
+    Ranges & ranges = *reinterpret_cast<Ranges *>(bank + bank_floats);
+
+    // -- backwards: index range needed on every edge --------------------------
+    if (threadIdx.x == 0)
+    {
+        ranges.fault = 0;
+        ranges.lo[stages] = first;
+        ranges.hi[stages] = last;
+
+        for (int k = stages - 1; k >= 0; k--)
+        {
+            // what stage k must produce, in its own output indexing
+            int const shift = chain.delay_edge == k + 1 ? call.delay : 0;
+            int const lo = ranges.lo[k + 1] - shift, hi = ranges.hi[k + 1] - shift;
+            Drb_Device_Stage const stage = chain.stages[k];
+
+            if (stage.kind == kStageUp2x)
+            {
+                ranges.lo[k] = floor_half(lo) - stage.taps + 1;
+                ranges.hi[k] = floor_half(hi - 1) + 1;
+            }
+            else if (stage.kind == kStageDown2x)
+            {
+                ranges.lo[k] = 2 * lo - 2 * stage.taps + 1;
+                ranges.hi[k] = 2 * hi - 2;
+            }
+            else
+            {
+                int consumed_lo, consumed_hi;
+                double unused;
+
+                sinc_position(call.phase + static_cast<long long>(lo) * chain.target_delta,
+                              chain.source_delta, chain.scale, chain.sinc_pull, consumed_lo, unused);
+                sinc_position(call.phase + static_cast<long long>(hi - 1) * chain.target_delta,
+                              chain.source_delta, chain.scale, chain.sinc_pull, consumed_hi, unused);
+
+                ranges.lo[k] = consumed_lo - stage.taps;
+                ranges.hi[k] = consumed_hi;
+            }
+        }
+
+        for (int e = 0; e <= stages; e++)
+        {
+            // every stage may read up to 15 floats past its range (discarded work items)
+            if (ranges.hi[e] - ranges.lo[e] + 16 > width) ranges.fault = 1;
+        }
+
+        int const source_shift = chain.delay_edge == 0 ? call.delay : 0;
+
+        if (ranges.lo[0] - source_shift < -chain.history) ranges.fault = 2;
+        if (ranges.hi[0] - source_shift > call.source_frames) ranges.fault = 3;
+
+        if (ranges.fault) atomicOr(fault_flag, ranges.fault);
+    }
+
+    // the fractional stage's coefficient bank, rows skewed by one float
+    if (bank_floats > 0)
+    {
+        for (int k = 0; k < stages; k++)
+        {
+            if (chain.stages[k].kind != kStageSinc) continue;
+
+            int const taps = chain.stages[k].taps;
+            int const rows = chain.stages[k].cubic ? 32 : 64;
+            float const * const source = table_at(chain.stages[k].table);
+
+            for (int i = threadIdx.x; i < rows * taps; i += kThreads)
+            {
+                bank[(i / taps) * (taps + 1) + i % taps] = source[i];
+            }
+        }
+    }
+
+    __syncthreads();
+
+    if (ranges.fault) return;
+
+    // -- load the source range -------------------------------------------------
+    {
+        int const lo = ranges.lo[0], count = ranges.hi[0] - ranges.lo[0];
+        int const shift = chain.delay_edge == 0 ? call.delay : 0;
+        int const split = stages > 0 && chain.stages[0].kind == kStageDown2x;
+        float const * const stream_history = history + static_cast<long long>(stream) * channels * chain.history;
+
+        if (chain.layout == kInterleaved)
+        {
+            for (int i = threadIdx.x; i < count * channels; i += kThreads)
+            {
+                int const position = i / channels, channel = i - position * channels;
+                float const v = source_frame(chain, call, stream_history, source_channel_stride,
+                                             channel, lo + position - shift);
+                put(buffers[0] + channel * width, width, split, position, v);
+            }
+        }
+        else
+        {
+            for (int channel = 0; channel < channels; channel++)
+            {
+                for (int position = threadIdx.x; position < count; position += kThreads)
+                {
+                    float const v = source_frame(chain, call, stream_history, source_channel_stride,
+                                                 channel, lo + position - shift);
+                    put(buffers[0] + channel * width, width, split, position, v);
+                }
+            }
+        }
+    }
+
+    __syncthreads();
+
+    // -- forwards: every stage LDS -> LDS --------------------------------------
+    for (int k = 0; k < stages; k++)
+    {
+        Drb_Device_Stage const stage = chain.stages[k];
+        float const * const in = buffers[k & 1];
+        float * const out = buffers[(k + 1) & 1];
+        int const shift = chain.delay_edge == k + 1 ? call.delay : 0;
+        int const lo = ranges.lo[k + 1] - shift, hi = ranges.hi[k + 1] - shift;
+        int const out_split = k + 1 < stages && chain.stages[k + 1].kind == kStageDown2x;
+        float const * const kernel = table_at(stage.table);
+
+        if (stage.kind == kStageSinc)
+        {
+            if (stage.taps == 32 && !stage.cubic)
+                stage_sinc<32, 0>(chain, call.phase, in, out, width, channels, out_split, lo, hi - lo, ranges.lo[k], bank);
+            else if (stage.taps == 32)
+                stage_sinc<32, 1>(chain, call.phase, in, out, width, channels, out_split, lo, hi - lo, ranges.lo[k], bank);
+            else if (!stage.cubic)
+                stage_sinc<16, 0>(chain, call.phase, in, out, width, channels, out_split, lo, hi - lo, ranges.lo[k], bank);
+            else
+                stage_sinc<16, 1>(chain, call.phase, in, out, width, channels, out_split, lo, hi - lo, ranges.lo[k], bank);
+        }
+        else
+        {
+            // up-sampler: source frames floor(lo/2) .. floor((hi-1)/2); its first
+            // output lands at position 2 floor(lo/2) - lo (0 or -1).
+            int const frames = stage.kind == kStageUp2x
+                ? floor_half(hi - 1) + 1 - floor_half(lo) : hi - lo;
+            int const out_offset = stage.kind == kStageUp2x ? 2 * floor_half(lo) - lo : 0;
+
+            switch (stage.taps)
+            {
+              case 8:  run_half_band<8>(stage.kind, in, out, width, channels, out_split, frames, out_offset, kernel); break;
+              case 16: run_half_band<16>(stage.kind, in, out, width, channels, out_split, frames, out_offset, kernel); break;
+              case 24: run_half_band<24>(stage.kind, in, out, width, channels, out_split, frames, out_offset, kernel); break;
+              case 32: run_half_band<32>(stage.kind, in, out, width, channels, out_split, frames, out_offset, kernel); break;
+              case 40: run_half_band<40>(stage.kind, in, out, width, channels, out_split, frames, out_offset, kernel); break;
+              default: run_half_band<48>(stage.kind, in, out, width, channels, out_split, frames, out_offset, kernel); break;
+            }
+        }
+
+        __syncthreads();
+    }
+
+    // -- store the tile ----------------------------------------------------------
+    {
+        float const * const result = buffers[stages & 1];
+        int const count = last - first;
+        void * const target = reinterpret_cast<void *>(call.target);
+
+        if (chain.layout == kInterleaved)
+        {
+            for (int i = threadIdx.x; i < count * channels; i += kThreads)
+            {
+                int const position = i / channels, channel = i - position * channels;
+                store_sample(target, static_cast<long long>(first + position) * channels + channel,
+                             chain.sample_type, result[channel * width + position]);
+            }
+        }
+        else
+        {
+            for (int channel = 0; channel < channels; channel++)
+            {
+                for (int position = threadIdx.x; position < count; position += kThreads)
+                {
+                    store_sample(target, channel * target_channel_stride + first + position,
+                                 chain.sample_type, result[channel * width + position]);
+                }
+            }
+        }
+    }
+}
+
+// New look-back per stream: the last `history` frames of (old history ++ chunk).
+__global__ __launch_bounds__(kThreads) void drb_history_kernel
+    (
+        Drb_Device_Chain const chain,
+        Drb_Device_Call const * __restrict__ calls,
+        float const * __restrict__ history_in, float * __restrict__ history_out,
+        long long source_channel_stride
+    )
+{
+    int const stream = blockIdx.x;
+    Drb_Device_Call const call = calls[stream];
+    long long const base = static_cast<long long>(stream) * chain.channels * chain.history;
+
+    for (int i = threadIdx.x; i < chain.channels * chain.history; i += kThreads)
+    {
+        int const channel = i / chain.history, slot = i - channel * chain.history;
+        int const frame = call.source_frames - chain.history + slot;
+
+        history_out[base + i] = source_frame(chain, call, history_in + base, source_channel_stride, channel, frame);
+    }
+}
+
+} // namespace
+
+// ---- C ABI --------------------------------------------------------------------
+
+extern "C" {
+
+int drb_hip_device_count (int * count) { return hipGetDeviceCount(count); }
+int drb_hip_get_device (int * device) { return hipGetDevice(device); }
+int drb_hip_set_device (int device) { return hipSetDevice(device); }
+
+int drb_hip_device_is_gfx950 (int device, int * yes, int * lds_bytes_per_block)
+{
+    hipDeviceProp_t properties;
+    hipError_t const status = hipGetDeviceProperties(&properties, device);
+
+    if (status != hipSuccess) return status;
+
+    // gcnArchName looks like "gfx950:sramecc+:xnack-"
+    char const * const name = properties.gcnArchName;
+
+    *yes = name[0] == 'g' && name[1] == 'f' && name[2] == 'x'
+        && name[3] == '9' && name[4] == '5' && name[5] == '0';
+    *lds_bytes_per_block = static_cast<int>(properties.sharedMemPerBlock);
+
+    return 0;
+}
+
+int drb_hip_alloc (void ** pointer, size_t bytes) { return hipMalloc(pointer, bytes); }
+int drb_hip_free (void * pointer) { return hipFree(pointer); }
+int drb_hip_host_alloc (void ** pointer, size_t bytes) { return hipHostMalloc(pointer, bytes, hipHostMallocDefault); }
+int drb_hip_host_free (void * pointer) { return hipHostFree(pointer); }
+
+int drb_hip_memset_async (void * pointer, int value, size_t bytes, void * stream)
+{
+    return hipMemsetAsync(pointer, value, bytes, static_cast<hipStream_t>(stream));
+}
+
+int drb_hip_upload_async (void * device, void const * host, size_t bytes, void * stream)
+{
+    return hipMemcpyAsync(device, host, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream));
+}
+
+int drb_hip_download_async (void * host, void const * device, size_t bytes, void * stream)
+{
+    return hipMemcpyAsync(host, device, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream));
+}
+
+int drb_hip_stream_synchronize (void * stream) { return hipStreamSynchronize(static_cast<hipStream_t>(stream)); }
+
+int drb_hip_event_create (void ** event)
+{
+    hipEvent_t created;
+    hipError_t const status = hipEventCreateWithFlags(&created, hipEventDisableTiming);
+    *event = created;
+    return status;
+}
+
+int drb_hip_timing_event_create (void ** event)
+{
+    hipEvent_t created;
+    hipError_t const status = hipEventCreate(&created);
+    *event = created;
+    return status;
+}
+
+int drb_hip_event_elapsed_ms (float * ms, void * start, void * stop)
+{
+    return hipEventElapsedTime(ms, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop));
+}
+
+int drb_hip_event_destroy (void * event) { return hipEventDestroy(static_cast<hipEvent_t>(event)); }
+int drb_hip_event_record (void * event, void * stream) { return hipEventRecord(static_cast<hipEvent_t>(event), static_cast<hipStream_t>(stream)); }
+int drb_hip_event_synchronize (void * event) { return hipEventSynchronize(static_cast<hipEvent_t>(event)); }
+char const * drb_hip_error_text (int code) { return hipGetErrorString(static_cast<hipError_t>(code)); }
+
+int drb_hip_launch_cascade
+    (
+        Drb_Device_Chain const * chain, int exact,
+        Drb_Device_Call const * calls, int stream_count, int max_tiles,
+        float const * history,
+        long long source_channel_stride, long long target_channel_stride,
+        int lds_bytes, int * fault_flag, void * stream
+    )
+{
+    (void)exact;
+
+    if (stream_count <= 0 || max_tiles <= 0) return 0;
+
+    int bank_floats = 0;
+
+    for (int k = 0; k < chain->stage_count; k++)
+    {
+        if (chain->stages[k].kind == kStageSinc)
+        {
+            bank_floats = (chain->stages[k].cubic ? 32 : 64) * (chain->stages[k].taps + 1);
+        }
+    }
+
+    size_t const dynamic = static_cast<size_t>(lds_bytes) + bank_floats * sizeof(float) + sizeof(Ranges);
+
+    static size_t raised = 0; // largest dynamic LDS size opted into so far
+
+    if (dynamic > 48 * 1024 && dynamic > raised)
+    {
+        hipError_t const status = hipFuncSetAttribute
+        (
+            reinterpret_cast<void const *>(drb_cascade_kernel),
+            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(dynamic)
+        );
+
+        if (status != hipSuccess) return status;
+
+        raised = dynamic;
+    }
+
+    long long const blocks = static_cast<long long>(stream_count) * max_tiles;
+
+    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+
+    drb_cascade_kernel<<<dim3(static_cast<unsigned>(blocks)), dim3(kThreads), dynamic, static_cast<hipStream_t>(stream)>>>
+    (
+        *chain, calls, stream_count, history,
+        source_channel_stride, target_channel_stride, bank_floats, fault_flag
+    );
+
+    return hipGetLastError();
+}
+
+int drb_hip_launch_history
+    (
+        Drb_Device_Chain const * chain,
+        Drb_Device_Call const * calls, int stream_count,
+        float const * history_in, float * history_out,
+        long long source_channel_stride, void * stream
+    )
+{
+    if (stream_count <= 0) return 0;
+
+    drb_history_kernel<<<dim3(stream_count), dim3(kThreads), 0, static_cast<hipStream_t>(stream)>>>
+    (
+        *chain, calls, history_in, history_out, source_channel_stride
+    );
+
+    return hipGetLastError();
+}
+
+} // extern "C"

@@ -1,0 +1,581 @@
+/*
+ * Host-side planner.  It must resolve every conversion to exactly the chain
+ * the upstream library builds (drb-audio-converter.c:2863-3234), because the
+ * chain fixes which filters run, the slicer's delay and the block-quantised
+ * frame counts.  The implementation is a small constraint solver over the
+ * edges between passes: every pass kind contributes one "settle" rule that
+ * fills in unknown (zero) fields of its two edges from the known ones.
+ */
+#include "drb_plan.h"
+
+#include <string.h>
+
+enum { layout_interleaved = 1, layout_planar = 2 };
+
+/* ---- validation (drb-audio-converter.c:3264-3364) ------------------------ */
+
+static int one_of (int value, int const * set, int count)
+{
+    for (int i = 0; i < count; i++)
+    {
+        if (set[i] == value) return 1;
+    }
+    return 0;
+}
+
+static int edge_is_valid (Drb_Edge const * edge)
+{
+    static int const rates [] =
+    {
+        8000, 11025, 16000, 22050, 44100, 48000, 60000,
+        88200, 96000, 120000, 176400, 192000, 240000
+    };
+    static int const blocks [] = { 1, 4, 16, 64, 256, 1024, 4096 };
+
+    return one_of(edge->rate, rates, 13)
+        && edge->channels >= 1 && edge->channels <= 8
+        && one_of(edge->block, blocks, 7)
+        && edge->max_blocks >= 0 && edge->max_blocks <= 8192
+        && edge->block * edge->max_blocks <= 8192;
+}
+
+/* ---- which passes (drb-audio-converter.c:2875-3077) ---------------------- */
+
+/* Smallest number of doublings of `low` after which the remaining ratio to
+ * `high` is closer to unity than one more doubling would leave it; the
+ * comparison is done in float, as upstream does (2887-2895, 2912-2920). */
+static int doublings (int low, int high)
+{
+    int count = 0;
+
+    while ((float)high / (low * (1 << count)) > (float)(low * (2 << count)) / high)
+    {
+        count++;
+    }
+
+    return count;
+}
+
+static int const half_band_orders [4][6] =
+{
+    /* poor */ { 48, 32, 16, 16, 16, 16 },
+    /* fine */ { 64, 48, 32, 16, 16, 16 },
+    /* good */ { 80, 64, 48, 32, 16, 16 },
+    /* best */ { 96, 80, 64, 48, 32, 16 }
+};
+
+static int const sinc_modes [4] = { 16, 116, 32, 132 }; /* taps + 100 * cubic */
+
+/* Lists the passes converting `from` to `to` (planning direction).  Returns
+ * the pass count, or -1 if upstream's tables would be overrun. */
+static int list_passes (Drb_Edge const * from, Drb_Edge const * to, int quality, Drb_Pass * passes)
+{
+    int up = 0, down = 0, fractional = 0;
+
+    if (from->rate < to->rate)
+    {
+        up = doublings(from->rate, to->rate);
+        fractional = from->rate * (1 << up) != to->rate;
+    }
+    else
+    {
+        down = doublings(to->rate, from->rate);
+        fractional = to->rate * (1 << down) != from->rate;
+    }
+
+    if (fractional && quality > 0) /* oversample around the fractional stage */
+    {
+        up++;
+        down++;
+    }
+
+    int const multichannel = from->channels > 1;
+    int const slicer = fractional || from->block < to->block;
+
+    if (up >= 6 || down >= 6) return -1;
+    if (2 * multichannel + up + down + fractional + slicer > drb_max_passes) return -1;
+
+    int count = 0;
+
+    if (multichannel) passes[count++] = (Drb_Pass){ drb_pass_interleave, 0 };
+
+    /* longest filter at the lowest rate, on both sides */
+    for (int i = 0; i < up; i++)
+    {
+        passes[count++] = (Drb_Pass){ drb_pass_up2x, half_band_orders[quality][i] };
+    }
+
+    if (fractional) passes[count++] = (Drb_Pass){ drb_pass_sinc, sinc_modes[quality] };
+    if (slicer) passes[count++] = (Drb_Pass){ drb_pass_slicer, 0 };
+
+    for (int i = down - 1; i >= 0; i--)
+    {
+        passes[count++] = (Drb_Pass){ drb_pass_down2x, half_band_orders[quality][i] };
+    }
+
+    if (multichannel) passes[count++] = (Drb_Pass){ drb_pass_deinterleave, 0 };
+
+    return count;
+}
+
+/* ---- edge formats (drb-audio-converter.c:3079-3157 and the per-pass
+ *      restrain functions 1413-1467, 1817-1893, 2366-2440, 2701-2753) ------- */
+
+static void agree (int * a, int * b)
+{
+    if (*a == 0 && *b > 0) *a = *b;
+    else if (*a > 0 && *b == 0) *b = *a;
+}
+
+static void scale_by_two (int * small, int * large)
+{
+    if (*small == 0 && *large > 0) *small = *large / 2;
+    if (*small > 0 && *large == 0) *large = *small * 2;
+}
+
+static void settle (Drb_Pass pass, Drb_Edge * a, Drb_Edge * b)
+{
+    switch (pass.kind)
+    {
+      case drb_pass_interleave:
+      case drb_pass_deinterleave:
+        if (a->layout == 0) a->layout = pass.kind == drb_pass_interleave ? layout_planar : layout_interleaved;
+        if (b->layout == 0) b->layout = pass.kind == drb_pass_interleave ? layout_interleaved : layout_planar;
+        agree(&a->rate, &b->rate);
+        agree(&a->channels, &b->channels);
+        agree(&a->block, &b->block);
+        agree(&a->max_blocks, &b->max_blocks);
+        break;
+
+      case drb_pass_up2x:
+        scale_by_two(&a->rate, &b->rate);
+        scale_by_two(&a->block, &b->block);
+        agree(&a->channels, &b->channels);
+        agree(&a->layout, &b->layout);
+        agree(&a->max_blocks, &b->max_blocks);
+        break;
+
+      case drb_pass_down2x:
+        scale_by_two(&b->rate, &a->rate);
+        scale_by_two(&b->block, &a->block);
+        agree(&a->channels, &b->channels);
+        agree(&a->layout, &b->layout);
+        agree(&a->max_blocks, &b->max_blocks);
+        break;
+
+      case drb_pass_sinc:
+        if (b->block == 0) b->block = 1;
+
+        if (a->rate > 0 && b->rate > 0 && a->block > 0 && b->block > 0)
+        {
+            if (a->max_blocks == 0 && b->max_blocks > 0)
+            {
+                /* most source frames that can never yield more target frames */
+                long frames = (long)b->max_blocks * b->block;
+                frames = frames * a->rate / b->rate;
+                a->max_blocks = (int)(frames / a->block);
+            }
+            else if (a->max_blocks > 0 && b->max_blocks == 0)
+            {
+                long frames = (long)a->max_blocks * a->block;
+                frames = (frames * b->rate + a->rate - 1) / a->rate;
+                b->max_blocks = (int)(frames / b->block);
+            }
+        }
+
+        agree(&a->channels, &b->channels);
+        agree(&a->layout, &b->layout);
+        break;
+
+      case drb_pass_slicer:
+        if (a->block > 0 && b->block > 0)
+        {
+            if (a->max_blocks == 0 && b->max_blocks > 0)
+            {
+                a->max_blocks = (int)((long)b->max_blocks * b->block / a->block);
+            }
+            else if (a->max_blocks > 0 && b->max_blocks == 0)
+            {
+                b->max_blocks = (int)(((long)a->max_blocks * a->block + b->block - 1) / b->block);
+            }
+        }
+
+        agree(&a->rate, &b->rate);
+        agree(&a->channels, &b->channels);
+        agree(&a->layout, &b->layout);
+        break;
+    }
+}
+
+static void settle_edges (Drb_Plan * plan, Drb_Edge const * from, Drb_Edge const * to)
+{
+    int const n = plan->pass_count;
+
+    memset(plan->edges, 0, sizeof(plan->edges));
+
+    plan->edges[0] = *from;
+    plan->edges[n] = *to; /* with no passes the far side wins, as upstream */
+
+    if (plan->edges[0].channels == 1) plan->edges[0].layout = layout_interleaved;
+    if (plan->edges[n].channels == 1) plan->edges[n].layout = layout_interleaved;
+
+    for (int round = 0; round < 2; round++)
+    {
+        for (int i = 0; i < n; i++) settle(plan->passes[i], &plan->edges[i], &plan->edges[i + 1]);
+        for (int i = n - 1; i >= 0; i--) settle(plan->passes[i], &plan->edges[i], &plan->edges[i + 1]);
+    }
+
+    if (n == 0)
+    {
+        plan->edges[0].max_blocks =
+            from->max_blocks > to->max_blocks ? from->max_blocks : to->max_blocks;
+    }
+}
+
+/* ---- sizes upstream reports ---------------------------------------------- */
+
+static long align64 (long size) { return (size + 63) & ~63L; }
+
+/* Bytes upstream's bump allocator hands out for a converter on an LP64 target
+ * (drb-audio-converter.c:53-88, 3690-3753): a 128-byte header plus 40 bytes per
+ * pass; per up-sampler a 16-byte header, one pointer and one double-length
+ * ring per channel (2206-2254); per down-sampler the same with two rings per
+ * channel (2295-2343); per fractional stage a 64-byte header, one pointer and
+ * one ring per channel (1743-1793); per slicer a 64-byte header plus one block
+ * (2676-2680).  Every allocation is rounded up to 64 bytes. */
+static long upstream_converter_size (Drb_Plan const * plan)
+{
+    long const ch = plan->channels;
+    long size = align64(128 + 40L * plan->pass_count);
+
+    for (int i = 0; i < plan->pass_count; i++)
+    {
+        Drb_Pass const pass = plan->passes[i];
+        long const ring = align64((pass.arg % 100) / (pass.kind == drb_pass_sinc ? 1 : 2) * 2 * 4L);
+
+        switch (pass.kind)
+        {
+          case drb_pass_up2x:
+            size += align64(16 + ch * 8) + ch * ring;
+            break;
+          case drb_pass_down2x:
+            size += align64(16 + ch * 2 * 8) + ch * 2 * ring;
+            break;
+          case drb_pass_sinc:
+            size += align64(64 + ch * 8) + ch * ring;
+            break;
+          case drb_pass_slicer:
+          {
+            long const a = plan->edges[i].block, b = plan->edges[i + 1].block;
+            size += align64(64 + (a > b ? a : b) * ch * 4);
+            break;
+          }
+        }
+    }
+
+    return size;
+}
+
+/* ---- resolve ------------------------------------------------------------- */
+
+int drb_plan_resolve
+    (
+        int source_rate, int target_rate, int channels,
+        int block_size, int max_block_count, int direction, int quality,
+        Drb_Plan * plan
+    )
+{
+    int const pull = direction == 1;
+
+    /* the user's block structure sits on the target side for push and on the
+     * source side for pull (drb-audio-converter.c:3926-3954) */
+    Drb_Edge const source =
+    {
+        source_rate, channels, layout_planar,
+        pull ? block_size : 1, pull ? max_block_count : 0
+    };
+    Drb_Edge const target =
+    {
+        target_rate, channels, layout_planar,
+        pull ? 1 : block_size, pull ? 0 : max_block_count
+    };
+
+    if (!edge_is_valid(&source) || !edge_is_valid(&target)) return 0;
+    if (quality < 0 || quality > 3) return 0;
+
+    memset(plan, 0, sizeof(*plan));
+
+    plan->source_rate = source_rate;
+    plan->target_rate = target_rate;
+    plan->channels = channels;
+    plan->block_size = block_size;
+    plan->max_block_count = max_block_count;
+    plan->direction = direction;
+    plan->quality = quality;
+
+    /* pull plans the opposite conversion, user side first, then swaps every
+     * pass for its inverse (drb-audio-converter.c:3191-3212, 2826-2859) */
+    Drb_Edge const * const from = pull ? &target : &source;
+    Drb_Edge const * const to = pull ? &source : &target;
+
+    plan->pass_count = list_passes(from, to, quality, plan->passes);
+
+    if (plan->pass_count < 0) return -1;
+
+    settle_edges(plan, from, to);
+
+    if (pull)
+    {
+        for (int i = 0; i < plan->pass_count; i++)
+        {
+            static int const inverse [] =
+            {
+                drb_pass_deinterleave, drb_pass_interleave,
+                drb_pass_down2x, drb_pass_up2x, drb_pass_sinc, drb_pass_slicer
+            };
+
+            plan->passes[i].kind = inverse[plan->passes[i].kind];
+        }
+    }
+
+    plan->throttling = plan->edges[0].block * plan->edges[0].max_blocks;
+
+    long floats = 0;
+
+    for (int i = 0; i <= plan->pass_count; i++)
+    {
+        long const need = (long)plan->edges[i].channels * plan->edges[i].block * plan->edges[i].max_blocks;
+        if (need > floats) floats = need;
+    }
+
+    plan->buffer_length = align64(floats * 4) / 4;
+    plan->converter_size = upstream_converter_size(plan);
+
+    /* DSP stages in data-flow order */
+    plan->sinc_stage = -1;
+
+    double macs = 0.0;
+    int granule = 1, odd_hazard = 0;
+
+    for (int k = 0; k < plan->pass_count; k++)
+    {
+        int const i = pull ? plan->pass_count - 1 - k : k;
+        Drb_Pass const pass = plan->passes[i];
+        Drb_Edge const * const in = pull ? &plan->edges[i + 1] : &plan->edges[i];
+        Drb_Edge const * const out = pull ? &plan->edges[i] : &plan->edges[i + 1];
+        Drb_Stage * const stage = &plan->stages[plan->stage_count];
+
+        stage->in_rate = in->rate;
+        stage->out_rate = out->rate;
+        stage->arg = pass.arg;
+
+        switch (pass.kind)
+        {
+          case drb_pass_up2x:
+            stage->kind = drb_stage_up2x;
+            macs += (double)(pass.arg / 2) * in->rate / target_rate;
+            break;
+          case drb_pass_down2x:
+            stage->kind = drb_stage_down2x;
+            macs += (double)(pass.arg / 2 + 1) * out->rate / target_rate;
+            break;
+          case drb_pass_sinc:
+          {
+            /* two (linear) or four (cubic) bank rows plus the blend */
+            int const taps = pass.arg % 100;
+            int const per_output = pass.arg >= 100 ? 4 * taps + 19 : 2 * taps + (taps == 32 ? 3 : 2);
+
+            stage->kind = drb_stage_sinc;
+            plan->sinc_stage = plan->stage_count;
+            plan->source_delta = (long long)(0x1.0p48 / in->rate);
+            plan->target_delta = (long long)(0x1.0p48 / out->rate);
+            macs += (double)per_output * out->rate / target_rate;
+            break;
+          }
+          case drb_pass_slicer:
+            stage->kind = drb_stage_delay;
+            stage->arg = in->block > out->block ? in->block : out->block;
+            plan->slicer_block = stage->arg;
+            break;
+          default:
+            continue; /* (de)interleaving is fused into the first load / last store */
+        }
+
+        plan->stage_count++;
+    }
+
+    plan->macs_per_output_sample = macs;
+
+    /* A 2x stage must never see an odd frame count.  Frame counts are
+     * quantised by the slicer; follow the guaranteed divisor along the chain
+     * from the side where the user hands in arbitrary counts. */
+    for (int k = 0; k < plan->stage_count; k++)
+    {
+        Drb_Stage const * const stage = &plan->stages[pull ? plan->stage_count - 1 - k : k];
+        int const doubling = stage->kind == (pull ? drb_stage_down2x : drb_stage_up2x);
+        int const halving = stage->kind == (pull ? drb_stage_up2x : drb_stage_down2x);
+
+        if (doubling) granule *= 2;
+        if (halving) { if (granule % 2) odd_hazard = 1; else granule /= 2; }
+        if (stage->kind == drb_stage_sinc) granule = 1;
+        if (stage->kind == drb_stage_delay) granule = stage->arg;
+    }
+
+    plan->runnable = plan->throttling > 0 && !odd_hazard;
+
+    return 1;
+}
+
+/* ---- per-stream frame arithmetic ----------------------------------------- */
+
+void drb_stream_reset (Drb_Plan const * plan, Drb_Stream_State * state)
+{
+    state->phase = plan->source_delta;            /* drb-audio-converter.c:1765 */
+    state->slicer_index = plan->slicer_block / 2; /* drb-audio-converter.c:2687 */
+}
+
+int drb_stream_step
+    (
+        Drb_Plan const * plan, Drb_Stream_State * state, int frames, Drb_Step * step
+    )
+{
+    int const pull = plan->direction == 1;
+    long long const sd = plan->source_delta, td = plan->target_delta;
+    long long count = frames;
+
+    step->phase = state->phase;
+    step->delay = 0;
+
+    /* push walks the chain with the data, pull against it */
+    for (int k = 0; k < plan->stage_count; k++)
+    {
+        Drb_Stage const * const stage = &plan->stages[pull ? plan->stage_count - 1 - k : k];
+
+        switch (stage->kind)
+        {
+          case drb_stage_up2x:
+            if (pull) { if (count & 1) return 0; count /= 2; } else count *= 2;
+            break;
+
+          case drb_stage_down2x:
+            if (pull) count *= 2; else { if (count & 1) return 0; count /= 2; }
+            break;
+
+          case drb_stage_sinc:
+            if (pull)
+            {
+                /* source frames consumed for `count` more outputs
+                 * (drb-audio-converter.c:1535-1538, 1677-1707) */
+                long long const consumed =
+                    count > 0 ? (state->phase - td + td * count) / sd : 0;
+
+                state->phase += td * count - sd * consumed;
+                count = consumed;
+            }
+            else
+            {
+                /* outputs released by `count` more source frames
+                 * (drb-audio-converter.c:1516-1519, 1617-1648) */
+                long long const produced =
+                    count > 0 ? (td - state->phase + sd * count) / td : 0;
+
+                state->phase += td * produced - sd * count;
+                count = produced;
+            }
+            break;
+
+          case drb_stage_delay:
+          {
+            /* whole blocks only; the block starts half full of silence
+             * (drb-audio-converter.c:2495-2499, 2502-2652).  Seen from the
+             * output side of the stage, sample j of this step is input sample
+             * j - delay of this step. */
+            int const block = stage->arg;
+            long long const filled = state->slicer_index + count;
+
+            step->delay = pull ? block - state->slicer_index : state->slicer_index;
+            state->slicer_index = (int)(filled % block);
+            count = filled / block * block;
+            break;
+          }
+        }
+    }
+
+    step->source_frames = pull ? (int)count : frames;
+    step->target_frames = pull ? frames : (int)count;
+
+    return 1;
+}
+
+/* ---- kernel geometry ------------------------------------------------------ */
+
+static long long floor_div (long long a, long long b)
+{
+    long long q = a / b;
+    if ((a % b != 0) && ((a < 0) != (b < 0))) q--;
+    return q;
+}
+
+/* Lowest input index (relative to the step) stage `stage` reads to produce
+ * output index `lo`, for the worst-case phase and delay. */
+static long long reach_back (Drb_Plan const * plan, Drb_Stage const * stage, long long lo)
+{
+    switch (stage->kind)
+    {
+      case drb_stage_up2x: return floor_div(lo, 2) - stage->arg / 2 + 1;
+      case drb_stage_down2x: return 2 * lo - stage->arg + 1;
+      case drb_stage_delay: return lo - stage->arg;
+      case drb_stage_sinc:
+        return floor_div(lo * plan->target_delta, plan->source_delta) - 2 - stage->arg % 100;
+    }
+    return lo;
+}
+
+/* Most input frames stage `stage` touches to produce `width` output frames. */
+static long long input_width (Drb_Plan const * plan, Drb_Stage const * stage, long long width)
+{
+    switch (stage->kind)
+    {
+      case drb_stage_up2x: return (width + 1) / 2 + stage->arg / 2 + 1;
+      case drb_stage_down2x: return 2 * width + stage->arg;
+      case drb_stage_delay: return width;
+      case drb_stage_sinc:
+        return (width * plan->target_delta + plan->source_delta - 1) / plan->source_delta
+             + stage->arg % 100 + 3;
+    }
+    return width;
+}
+
+void drb_plan_geometry (Drb_Plan const * plan, int lds_budget_bytes, Drb_Geometry * geometry)
+{
+    long long lo = 0;
+
+    for (int k = plan->stage_count - 1; k >= 0; k--)
+    {
+        lo = reach_back(plan, &plan->stages[k], lo);
+    }
+
+    geometry->history_frames = (int)((-lo + 3) / 4 * 4);
+    if (geometry->history_frames < 4) geometry->history_frames = 4;
+
+    static int const tiles [] = { 2048, 1024, 512, 256, 128, 64, 32, 16 };
+
+    for (unsigned t = 0; t < sizeof(tiles) / sizeof(tiles[0]); t++)
+    {
+        long long width = tiles[t], widest = tiles[t];
+
+        for (int k = plan->stage_count - 1; k >= 0; k--)
+        {
+            width = input_width(plan, &plan->stages[k], width);
+            if (width > widest) widest = width;
+        }
+
+        widest = (widest + 3) / 4 * 4;
+
+        geometry->tile_frames = tiles[t];
+        geometry->lds_width = (int)widest;
+        geometry->lds_bytes = (int)(2 * widest * plan->channels * 4);
+
+        if (geometry->lds_bytes <= lds_budget_bytes) break;
+    }
+}

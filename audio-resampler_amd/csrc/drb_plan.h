@@ -1,0 +1,124 @@
+/* Host-side planning: which passes run for a conversion, the frame-count
+ * arithmetic of every stage, and the sizes the GPU kernels need. */
+#ifndef DRB_PLAN_H
+#define DRB_PLAN_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum
+{
+    drb_pass_interleave = 0,
+    drb_pass_deinterleave = 1,
+    drb_pass_up2x = 2,      /* arg = half-band order           */
+    drb_pass_down2x = 3,    /* arg = half-band order           */
+    drb_pass_sinc = 4,      /* arg = taps + 100 * cubic        */
+    drb_pass_slicer = 5
+};
+
+enum
+{
+    drb_stage_up2x = 1,
+    drb_stage_down2x = 2,
+    drb_stage_sinc = 3,
+    drb_stage_delay = 4     /* the slicer, seen as a pure delay; arg = block B */
+};
+
+enum { drb_max_passes = 10, drb_max_stages = 8 };
+
+typedef struct Drb_Edge
+{
+    int rate, channels, layout, block, max_blocks;
+}
+Drb_Edge;
+
+typedef struct Drb_Pass { int kind, arg; } Drb_Pass;
+
+typedef struct Drb_Stage { int kind, arg, in_rate, out_rate; } Drb_Stage;
+
+typedef struct Drb_Plan
+{
+    int source_rate, target_rate, channels, block_size, max_block_count;
+    int direction, quality;
+
+    /* planning order, as upstream lists it: for pull, index 0 is the user's
+     * (target) side and data flows from the last pass to the first */
+    int pass_count;
+    Drb_Pass passes [drb_max_passes];
+    Drb_Edge edges [drb_max_passes + 1];
+
+    int throttling;          /* user-side frames per driver sub-block  */
+    long buffer_length;      /* floats per work buffer                 */
+    long converter_size;     /* bytes upstream's converter block takes */
+
+    /* DSP stages in data-flow order ((de)interleaving is not a stage) */
+    int stage_count;
+    Drb_Stage stages [drb_max_stages];
+    int slicer_block;        /* 0 = no slicer                          */
+    int sinc_stage;          /* index into stages, -1 = none           */
+    long long source_delta;  /* 2^48 / sinc input rate                 */
+    long long target_delta;  /* 2^48 / sinc output rate                */
+    int runnable;            /* 0: see drb_plan_resolve                */
+    double macs_per_output_sample;
+}
+Drb_Plan;
+
+/* 1 = resolved; 0 = rejected by validation; -1 = needs six or more 2x stages
+ * or more than ten passes (outside upstream's tables).  plan->runnable is 0
+ * when the driver could not run it: zero throttling, or a 2x stage exposed to
+ * odd frame counts. */
+int drb_plan_resolve
+    (
+        int source_rate, int target_rate, int channels,
+        int block_size, int max_block_count, int direction, int quality,
+        Drb_Plan * plan
+    );
+
+/* ---- per-stream frame arithmetic ---------------------------------------- */
+
+typedef struct Drb_Stream_State
+{
+    long long phase;        /* fractional stage accumulator              */
+    int slicer_index;       /* frames held in the slicer's block         */
+}
+Drb_Stream_State;
+
+/* What the device needs to know about one stream for one step. */
+typedef struct Drb_Step
+{
+    int source_frames;      /* consumed                                   */
+    int target_frames;      /* produced                                   */
+    long long phase;        /* accumulator at the start of the step       */
+    int delay;              /* frames the delay stage shifts by this step */
+}
+Drb_Step;
+
+void drb_stream_reset (Drb_Plan const * plan, Drb_Stream_State * state);
+
+/* Advances `state` by one step of `frames` user-side frames (push: source
+ * frames offered, pull: target frames wanted) and reports the step.  Returns
+ * 0 if a 2x stage would see an odd frame count. */
+int drb_stream_step
+    (
+        Drb_Plan const * plan, Drb_Stream_State * state, int frames, Drb_Step * step
+    );
+
+/* ---- kernel geometry ----------------------------------------------------- */
+
+typedef struct Drb_Geometry
+{
+    int history_frames;     /* source frames of look-back kept per stream      */
+    int tile_frames;        /* target frames per workgroup                      */
+    int lds_width;          /* floats per channel per staging buffer            */
+    int lds_bytes;          /* dynamic LDS per workgroup                        */
+}
+Drb_Geometry;
+
+void drb_plan_geometry (Drb_Plan const * plan, int lds_budget_bytes, Drb_Geometry * geometry);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""Headline benchmark: output Msamples/s of the batched resampling path.
+
+One step = every stream of the batch pushes `--seconds` of synthetic white
+noise through the cascade (state carried from step to step), with the source
+and target buffers already resident in HBM.  N > 1 runs one process per GPU
+(torch.distributed over RCCL is used for the barrier and the max-over-ranks
+only; streams are independent, there is no collective on the data path), each
+rank owning its own `--streams` streams: weak scaling.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for path in (os.path.join(ROOT, "audio-resampler_amd"), os.path.join(ROOT, "tests")):
+    if path not in sys.path:
+        sys.path.insert(0, path)
+
+WORKLOADS = {
+    # name: (src, dst, channels, block, max_blocks, direction, quality, sample, layout, streams)
+    "headline": (44100, 48000, 2, 256, 16, 0, 2, "f32", "planar", 1024),
+    "headline_poor": (44100, 48000, 2, 256, 16, 0, 0, "f32", "planar", 1024),
+    "headline_best": (44100, 48000, 2, 256, 16, 0, 3, "f32", "planar", 1024),
+    "cfg2_i16": (48000, 44100, 2, 256, 16, 0, 2, "i16", "interleaved", 1024),
+    "cfg3_8ch": (96000, 48000, 8, 256, 16, 0, 2, "f32", "planar", 512),
+    "cfg4_mono_pull": (16000, 48000, 1, 256, 16, 1, 2, "f32", "planar", 8192),
+    "cfg5_i32_best": (192000, 44100, 2, 256, 16, 0, 3, "i32", "interleaved", 256),
+}
+
+FP32_PEAK_TFLOPS = 157.3   # MI355X fp32 vector = fp32 MFMA peak
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec
+
+
+def cpu_baseline(workload, seconds_budget=12.0):
+    """The upstream converter (oracle/_ref, compiled from its own source) or,
+    where that build is absent, the CPU restatement, one instance per thread,
+    4096-frame process() calls, scalar build flags."""
+    import concurrent.futures
+
+    import numpy as np
+
+    import support
+
+    src, dst, ch, bs, mbc, direction, quality = workload[:7]
+    threads = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "8")), os.cpu_count() or 1))
+    frames = src  # one second per conversion
+    x = support.white_noise(ch, frames, 1)
+    if support.have_ref():
+        kind, harness = "reference", support.ref_harness()
+
+        def convert():
+            if direction == 0:
+                y, _ = harness.push(src, dst, ch, bs, mbc, quality, x, [4096] * (frames // 4096))
+                return y.size
+            want = int(frames * dst / src * 0.9)
+            y, _, _ = harness.pull(src, dst, ch, bs, mbc, quality, x, [4096] * (want // 4096))
+            return y.size
+    else:
+        kind = "port"
+        status, plan = support.oracle_plan(src, dst, ch, bs, mbc, direction, quality)
+        assert status == 1
+
+        def convert():
+            if direction == 0:
+                return support.oracle_push(plan, x).size
+            return support.oracle_pull(plan, x, int(frames * dst / src * 0.9))[0].size
+
+    def worker(_):
+        done, start = 0, time.perf_counter()
+        while time.perf_counter() - start < seconds_budget:
+            done += convert()
+        return done, time.perf_counter() - start
+
+    convert()  # page in
+    with concurrent.futures.ThreadPoolExecutor(threads) as pool:
+        results = list(pool.map(worker, range(threads)))
+    rate = sum(done / elapsed for done, elapsed in results) / 1e6
+    return {"value": round(rate, 3), "unit": "Msamples/s", "cores": threads, "kind": kind,
+            "sample": "%d threads x repeated 1 s conversions of the same workload shape for %.0f s, "
+                      "4096-frame process() calls" % (threads, seconds_budget)}
+
+
+def main():
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--gpus", type=int, default=1)
+    parser.add_argument("--steps", type=int, default=20)
+    parser.add_argument("--warmup", type=int, default=3)
+    parser.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
+    parser.add_argument("--streams", type=int, default=0, help="streams per GPU (0 = workload default)")
+    parser.add_argument("--seconds", type=float, default=1.0, help="audio seconds per stream per step")
+    parser.add_argument("--arithmetic", default="fast", choices=["exact", "fast"])
+    parser.add_argument("--no-cpu-baseline", action="store_true")
+    args = parser.parse_args()
+
+    import torch
+
+    import drbamd
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, "launch with --nproc-per-node equal to --gpus"
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    src, dst, ch, bs, mbc, direction, quality, sample, layout, default_streams = WORKLOADS[args.workload]
+    streams = args.streams or default_streams
+    sample_type = {"f32": drbamd.F32, "i16": drbamd.I16, "i32": drbamd.I32}[sample]
+    torch_type = {"f32": torch.float32, "i16": torch.int16, "i32": torch.int32}[sample]
+    config = drbamd.make_config(src, dst, ch, bs, mbc, direction, quality, sample_type=sample_type,
+                                layout=drbamd.INTERLEAVED if layout == "interleaved" else drbamd.PLANAR,
+                                arithmetic=drbamd.EXACT if args.arithmetic == "exact" else drbamd.FAST,
+                                streams=streams, device=local_rank)
+    info = drbamd.plan_info(config)
+    batch = drbamd.Batch(config)
+
+    # user-side frames per step: push = source frames, pull = target frames
+    user_rate = dst if direction == 1 else src
+    frames = int(round(args.seconds * user_rate / bs)) * bs
+    other = batch.query([frames] * streams)[0]
+    source_frames = other + 4096 if direction == 1 else frames
+    target_capacity = frames if direction == 1 else other + 4096
+
+    generator = torch.Generator(device=device)
+    generator.manual_seed(1234 + rank)
+    noise = torch.rand((streams, ch, source_frames), device=device, generator=generator) * 2 - 1
+    if layout == "interleaved":
+        noise = noise.transpose(1, 2).contiguous()
+    if sample == "i16":
+        source = (noise * 32767).round().to(torch.int16)
+    elif sample == "i32":
+        source = (noise.double() * 2147483647).round().to(torch.int32)
+    else:
+        source = noise
+    del noise
+    target = torch.zeros(streams * ch * target_capacity, dtype=torch_type, device=device)
+    produced = (ctypes.c_int * streams)()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        batch.process_dense(source.data_ptr(), ch * source_frames, source_frames,
+                            target.data_ptr(), ch * target_capacity, target_capacity,
+                            frames, source_frames if direction == 1 else target_capacity,
+                            stream=stream, produced=produced)
+        return sum(produced) if direction == 0 else frames * streams
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    start = time.perf_counter()
+    out_frames = 0
+    for _ in range(args.steps):
+        out_frames += step()
+    barrier()
+    elapsed = time.perf_counter() - start
+    batch.synchronize(stream)
+
+    totals = torch.tensor([elapsed, float(out_frames)], dtype=torch.float64, device=device)
+    if world > 1:
+        slowest = totals[:1].clone()
+        dist.all_reduce(slowest, op=dist.ReduceOp.MAX)
+        frames_sum = totals[1:].clone()
+        dist.all_reduce(frames_sum, op=dist.ReduceOp.SUM)
+        elapsed, all_frames = slowest.item(), frames_sum.item()
+    else:
+        all_frames = float(out_frames)
+    samples = all_frames * ch
+    value = samples / elapsed / 1e6
+
+    # dominant kernel: duration from HIP events on the launch stream
+    batch.time_kernels(True)
+    kernel_ms, kernel_samples = [], []
+    for _ in range(max(3, min(args.steps, 10))):
+        n = step()
+        kernel_ms.append(batch.kernel_ms())
+        kernel_samples.append(n * ch)
+    batch.time_kernels(False)
+    mean_ms = sum(kernel_ms) / len(kernel_ms)
+    mean_samples = sum(kernel_samples) / len(kernel_samples)
+    flops = info.flops_per_output_sample * mean_samples
+    nbytes = info.bytes_per_output_sample * mean_samples
+    compute_frac = flops / (mean_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS
+    memory_frac = nbytes / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    if compute_frac >= memory_frac:
+        roofline = {"bound": "mfma", "achieved": round(flops / (mean_ms * 1e-3) / 1e12, 3),
+                    "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(compute_frac, 4)}
+    else:
+        roofline = {"bound": "hbm", "achieved": round(nbytes / (mean_ms * 1e-3) / 1e9, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(memory_frac, 4)}
+    roofline.update({"traffic": None, "kernel": "drb_cascade_kernel", "kernel_ms": round(mean_ms, 4),
+                     "algorithmic_flops_per_sample": round(info.flops_per_output_sample, 1),
+                     "algorithmic_bytes_per_sample": round(info.bytes_per_output_sample, 3),
+                     "other_roofline_frac": round(min(compute_frac, memory_frac), 4)})
+
+    if rank == 0:
+        line = {
+            "metric": "output Msamples/s, 1024 stereo 44.1->48k streams",
+            "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic white noise, uniform [-1, 1)",
+            "config": {"workload": "%d x %d-ch %s %d->%d Hz per GPU, quality %s, %s, %s layout, %.2f s per step, %s arithmetic"
+                                   % (streams, ch, sample, src, dst, ["poor", "fine", "good", "best"][quality],
+                                      "pull" if direction else "push", layout, args.seconds, args.arithmetic),
+                       "name": args.workload, "streams_per_gpu": streams, "frames_per_step": frames,
+                       "tile_frames": info.tile_frames, "history_frames": info.history_frames},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(WORKLOADS[args.workload])
+        print(json.dumps(line), flush=True)
+
+    batch.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,84 @@
+"""The four-function drop-in (drb_audio_converter_*) running on the GPU,
+driven by the same harness that drives the upstream build: same sample
+stream, same callback frame counts, same example program output."""
+import numpy as np
+import pytest
+
+import golden_data
+import support
+from support import PUSH, PULL
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+drbamd = pytest.importorskip("drbamd")
+
+META, DATA = golden_data.streams()
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def harness():
+    return support.ApiHarness(drbamd.HARNESS_PATH)
+
+
+NAMES = ["cfg1_push_good", "cfg1_pull_good", "cfg2_push_good", "cfg3_push_good", "cfg4_pull_good",
+         "cfg5_push_best", "cfg1_push_good_bs1", "same_rate_reblock", "up2_push_bs1"]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_drop_in_stream_and_callbacks(harness, name):
+    meta = META[name]
+    args = (meta["src"], meta["dst"], meta["channels"], meta["block_size"], meta["max_block_count"], meta["quality"])
+    x = DATA["%s.noise.in" % name]
+    want = DATA["%s.noise.out" % name]
+    if meta["direction"] == PUSH:
+        got, _ = harness.push(*args, x, [x.shape[1]])
+    else:
+        got, _, consumed = harness.pull(*args, x, [want.shape[1]])
+        assert consumed == meta["used"]
+    assert got.shape == want.shape
+    assert np.array_equal(bits(got), bits(want))
+    for sched in meta["callbacks"].values():
+        big = support.white_noise(meta["channels"], 200000, 3)
+        if meta["direction"] == PUSH:
+            _, counts = harness.push(*args, big, sched["chunks"])
+        else:
+            _, counts, _ = harness.pull(*args, big, sched["chunks"])
+        assert counts.tolist() == sched["counts"]
+
+
+def test_sizes_match_upstream(harness):
+    for row in golden_data.planner_rows()[::97]:
+        if row[7] in ("rejected", "unsupported"):
+            assert harness.sizes(*row[:7]) == (0, 0)
+            continue
+        status, plan = support.oracle_plan(*row[:7])
+        if status != 1 or not plan.consistent:
+            continue
+        assert harness.sizes(*row[:7]) == (row[11], row[12]), row
+
+
+def format_example(frames):
+    return "".join("%3d" % i + "".join(", %8.3f" % v for v in frames[:, i]) + "\n"
+                   for i in range(frames.shape[1]))
+
+
+def test_example_push_program_output(harness):
+    slices = [13, 17, 4, 7, 5, 4, 21, 29, 300]
+    x = np.stack([np.arange(500) + 100.0 * c for c in range(2)]).astype(np.float32)
+    y, counts = harness.push(44100, 48000, 2, 4, 64, support.GOOD, x, slices)
+    assert all(c % 4 == 0 for c in counts)
+    assert format_example(y) == golden_data.example_text("example_push")
+
+
+def test_example_pull_program_output(harness):
+    slices = [13, 17, 4, 7, 5, 4, 21, 29, 300]
+    x = np.stack([np.arange(4000) + 100.0 * c for c in range(2)]).astype(np.float32)
+    y, counts, _ = harness.pull(44100, 48000, 2, 4, 256, support.GOOD, x, slices)
+    assert all(c % 4 == 0 for c in counts)
+    want = golden_data.example_text("example_pull").splitlines()[:sum(slices)]
+    assert format_example(y).splitlines() == want

@@ -1,0 +1,95 @@
+"""Host-side logic of the product library against the golden planner matrix:
+pass chains, edge formats, throttling, work-buffer length and converter sizes
+must be exactly what the upstream planner resolves.  No GPU needed: these entry
+points never touch the device."""
+import ctypes
+
+import pytest
+
+import golden_data
+import support
+
+drbamd = pytest.importorskip("drbamd")
+
+
+def config_of(row):
+    src, dst, ch, bs, mbc, direction, quality = row[:7]
+    return drbamd.make_config(src, dst, ch, bs, mbc, direction, quality)
+
+
+def test_planner_matrix_matches_upstream():
+    checked = rejected = 0
+    for row in golden_data.planner_rows():
+        src, dst, ch, bs, mbc, direction, quality = row[:7]
+        described = drbamd.plan_describe(config_of(row))
+        sizes = drbamd.converter_size(src, dst, ch, bs, mbc, direction, quality)
+        if row[7] in ("rejected", "unsupported"):
+            assert described is None and sizes is None, row
+            rejected += 1
+            continue
+        passes, formats, throttling, buffer_length, size, work = row[7:13]
+        assert described is not None, row
+        got_passes, got_edges, got_throttling, got_length = described
+        assert got_passes == passes, row
+        assert got_edges == formats, row
+        assert got_throttling == throttling, row
+        assert got_length == buffer_length, row
+        assert sizes == (64, size), row
+        assert work == buffer_length * 2 * 4, row
+        checked += 1
+    assert checked > 5000 and rejected > 0
+
+
+def test_plan_info_agrees_with_oracle_plan():
+    for row in golden_data.planner_rows()[::7]:
+        if row[7] in ("rejected", "unsupported"):
+            continue
+        src, dst, ch, bs, mbc, direction, quality = row[:7]
+        status, plan = support.oracle_plan(src, dst, ch, bs, mbc, direction, quality)
+        try:
+            info = drbamd.plan_info(config_of(row))
+        except drbamd.DrbError as error:
+            assert error.status == "unsupported"
+            assert status == -1 or not plan.consistent, row
+            continue
+        assert status == 1 and plan.consistent, row
+        assert info.stages() == plan.stages(), row
+        assert info.throttling == plan.throttling, row
+        assert info.history_frames >= 4 and info.tile_frames >= 16
+
+
+def test_flops_and_bytes_per_output_sample():
+    # work per target sample of the cascade as written, 2 x MACs
+    cases = {
+        (44100, 48000, 2, support.GOOD, drbamd.F32): (424, 7.675),
+        (44100, 48000, 2, support.POOR, drbamd.F32): (68, 7.675),
+        (44100, 48000, 2, support.FINE, drbamd.F32): (456, 7.675),
+        (44100, 48000, 2, support.BEST, drbamd.F32): (774, 7.675),
+        (48000, 44100, 2, support.GOOD, drbamd.I16): (438, 4.177),
+        (96000, 48000, 8, support.GOOD, drbamd.F32): (82, 12.0),
+        (192000, 44100, 2, support.BEST, drbamd.I32): (3296, 21.415),
+    }
+    for (src, dst, ch, quality, sample), (flops, nbytes) in cases.items():
+        config = drbamd.make_config(src, dst, ch, 256, 16, support.PUSH, quality, sample_type=sample)
+        info = drbamd.plan_info(config)
+        assert abs(info.flops_per_output_sample - flops) <= 0.01 * flops + 1, (src, dst, quality)
+        assert abs(info.bytes_per_output_sample - nbytes) < 0.01
+
+
+def test_library_exports_every_declared_symbol():
+    names = ["drb_audio_converter_alignment_and_size", "drb_audio_converter_construct",
+             "drb_audio_converter_work_memory_alignment_and_size", "drb_audio_converter_process",
+             "drb_amd_converter_release", "drb_amd_batch_create", "drb_amd_batch_destroy",
+             "drb_amd_batch_reset", "drb_amd_batch_query", "drb_amd_batch_process",
+             "drb_amd_batch_process_dense", "drb_amd_batch_synchronize", "drb_amd_plan_info",
+             "drb_amd_batch_time_kernels", "drb_amd_batch_kernel_ms",
+             "drb_amd_plan_describe", "drb_amd_last_error"]
+    import re
+    header = open(support.ROOT + "/include/drb_audio_converter_amd.h").read()
+    declared = set(re.findall(r"\b(drb_a\w+)\s*\n?\s*\(", header))
+    declared -= {"drb_audio_converter_version"}
+    assert declared == set(names), declared ^ set(names)
+    for name in names:
+        assert getattr(drbamd.lib, name) is not None
+    harness = ctypes.CDLL(drbamd.HARNESS_PATH)
+    assert harness.harness_push and harness.harness_pull and harness.harness_sizes
