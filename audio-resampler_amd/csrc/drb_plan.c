@@ -555,7 +555,7 @@ void drb_plan_geometry (Drb_Plan const * plan, int lds_budget_bytes, Drb_Geometr
         lo = reach_back(plan, &plan->stages[k], lo);
     }
 
-    geometry->history_frames = (int)((-lo + 3) / 4 * 4);
+    geometry->history_frames = (int)((-lo + 4 + 3) / 4 * 4);
     if (geometry->history_frames < 4) geometry->history_frames = 4;
 
     static int const tiles [] = { 2048, 1024, 512, 256, 128, 64, 32, 16 };
@@ -570,7 +570,9 @@ void drb_plan_geometry (Drb_Plan const * plan, int lds_budget_bytes, Drb_Geometr
             if (width > widest) widest = width;
         }
 
-        widest = (widest + 3) / 4 * 4;
+        /* stages read whole 4-float groups, up to 15 floats past their range;
+         * two-plane edges split the width in halves of whole groups */
+        widest = (widest + 16 + 7) / 8 * 8;
 
         geometry->tile_frames = tiles[t];
         geometry->lds_width = (int)widest;

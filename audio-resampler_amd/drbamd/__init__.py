@@ -25,6 +25,14 @@ if not os.path.exists(LIB_PATH):
     raise ImportError("%s is missing: build it with `make -C audio-resampler_amd/csrc` "
                       "(or __graft_entry__.build())" % LIB_PATH)
 
+# One HIP runtime per process: torch wheels bundle their own libamdhip64 (same
+# SONAME as the system one).  Loading torch first makes this library bind to
+# that copy instead of bringing a second runtime, which would see no device.
+try:
+    import torch  # noqa: F401
+except ImportError:  # plain C users link the system runtime
+    pass
+
 lib = ctypes.CDLL(LIB_PATH)
 
 
