@@ -172,15 +172,9 @@ def main():
     elapsed = time.perf_counter() - start
     batch.synchronize(stream)
 
-    totals = torch.tensor([elapsed, float(out_frames)], dtype=torch.float64, device=device)
-    if world > 1:
-        slowest = totals[:1].clone()
-        dist.all_reduce(slowest, op=dist.ReduceOp.MAX)
-        frames_sum = totals[1:].clone()
-        dist.all_reduce(frames_sum, op=dist.ReduceOp.SUM)
-        elapsed, all_frames = slowest.item(), frames_sum.item()
-    else:
-        all_frames = float(out_frames)
+    from drbamd import sharding
+
+    elapsed, all_frames = sharding.reduce_step_stats(elapsed, out_frames, device=device)
     samples = all_frames * ch
     value = samples / elapsed / 1e6
 

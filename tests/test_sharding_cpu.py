@@ -1,0 +1,71 @@
+"""The N > 1 path on CPU: two gloo ranks shard a set of streams, convert their
+shard with the CPU restatement (the GPU library cannot run here) and agree on
+timing statistics.  Checks that sharding by stream is invisible in the results
+and that the reduction bench.py reports (max time, summed frames) is right."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import support
+from support import PUSH
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, total_streams, out_dir):
+    sys.path.insert(0, os.path.join(support.ROOT, "audio-resampler_amd"))
+    from drbamd import sharding
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    first, last = sharding.shard_range(total_streams, rank, world)
+    status, plan = support.oracle_plan(44100, 48000, 2, 4, 64, PUSH, support.GOOD)
+    assert status == 1
+    frames = 0
+    for s in range(first, last):
+        y = support.oracle_push(plan, support.white_noise(2, 1500 + 10 * s, 900 + s))
+        np.save(os.path.join(out_dir, "stream%03d.npy" % s), y)
+        frames += y.shape[1]
+    slowest, total = sharding.reduce_step_stats(1.0 + rank, frames)
+    np.save(os.path.join(out_dir, "stats%d.npy" % rank), np.array([slowest, total, first, last]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_shard_streams(tmp_path):
+    world, total_streams = 2, 7
+    mp.spawn(_worker, args=(world, _free_port(), total_streams, str(tmp_path)), nprocs=world, join=True)
+    status, plan = support.oracle_plan(44100, 48000, 2, 4, 64, PUSH, support.GOOD)
+    frames = 0
+    for s in range(total_streams):
+        want = support.oracle_push(plan, support.white_noise(2, 1500 + 10 * s, 900 + s))
+        got = np.load(tmp_path / ("stream%03d.npy" % s))
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        frames += want.shape[1]
+    stats = [np.load(tmp_path / ("stats%d.npy" % r)) for r in range(world)]
+    assert [int(v) for v in stats[0][2:]] == [0, 4] and [int(v) for v in stats[1][2:]] == [4, 7]
+    for row in stats:
+        assert row[0] == 2.0           # max over ranks of (1.0, 2.0)
+        assert row[1] == float(frames)  # frames summed over ranks
+
+
+def test_shard_ranges_partition_the_streams():
+    sys.path.insert(0, os.path.join(support.ROOT, "audio-resampler_amd"))
+    from drbamd import sharding
+
+    for total in (0, 1, 7, 1024, 4096, 65536):
+        for world in (1, 2, 4, 8):
+            edges = [sharding.shard_range(total, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
+            sizes = [b - a for a, b in edges]
+            assert max(sizes) - min(sizes) <= 1
