@@ -27,6 +27,7 @@ struct DrbAmd_Batch
     Drb_Plan plan;
     Drb_Geometry geometry;
     Drb_Device_Chain chain;
+    Drb_Fast_Chain fast;              /* matrix-core path, when the plan has its shape */
     int device;
     int sample_bytes;
 
@@ -162,7 +163,7 @@ static DrbAmd_Status resolve (DrbAmd_Batch_Config const * config, Drb_Plan * pla
     return drb_amd_ok;
 }
 
-enum { lds_budget = 56 * 1024 };
+enum { lds_budget = 56 * 1024, fast_lds_budget = 78 * 1024 };
 
 DrbAmd_Status drb_amd_plan_info (DrbAmd_Batch_Config const * config, DrbAmd_Plan_Info * info)
 {
@@ -197,6 +198,12 @@ DrbAmd_Status drb_amd_plan_info (DrbAmd_Batch_Config const * config, DrbAmd_Plan
     info->flops_per_output_sample = 2.0 * plan.macs_per_output_sample;
     info->bytes_per_output_sample =
         sample_bytes * ((double)plan.source_rate / plan.target_rate) + sample_bytes;
+
+    Drb_Fast_Chain fast;
+
+    drb_plan_fast_geometry(&plan, fast_lds_budget, &fast);
+    info->fast_path = fast.usable;
+    info->fast_tile_frames = fast.tile_frames;
 
     return drb_amd_ok;
 }
@@ -310,6 +317,11 @@ DrbAmd_Status drb_amd_batch_create (DrbAmd_Batch_Config const * config, DrbAmd_B
 
     drb_plan_geometry(&plan, lds_budget, &batch->geometry);
     build_chain(config, &plan, &batch->geometry, &batch->chain);
+
+    drb_plan_fast_geometry(&plan, fast_lds_budget, &batch->fast);
+    batch->fast.sample_type = config->sample_type;
+    batch->fast.layout = config->layout;
+    batch->fast.history = batch->geometry.history_frames;
 
     size_t const n = (size_t)config->stream_count;
 
@@ -505,11 +517,22 @@ DrbAmd_Status drb_amd_batch_process
 
     if (!code && batch->timing) code = drb_hip_event_record(batch->kernel_start, hip_stream);
 
-    if (!code)
+    if (!code && batch->config.arithmetic == drb_amd_arithmetic_fast && batch->fast.usable)
+    {
+        int const fast_tile = batch->fast.tile_frames;
+
+        code = drb_hip_launch_fast
+        (
+            &batch->fast, batch->calls_device, n, (most_target + fast_tile - 1) / fast_tile,
+            history_in, source_channel_stride, target_channel_stride,
+            batch->fault_device, hip_stream
+        );
+    }
+    else if (!code)
     {
         code = drb_hip_launch_cascade
         (
-            &batch->chain, batch->config.arithmetic == drb_amd_arithmetic_exact,
+            &batch->chain, 1,
             batch->calls_device, n, (most_target + tile - 1) / tile, history_in,
             source_channel_stride, target_channel_stride,
             batch->geometry.lds_bytes, batch->fault_device, hip_stream

@@ -54,6 +54,34 @@ typedef struct Drb_Device_Call
 }
 Drb_Device_Call;
 
+/* Geometry of the matrix-core ("fast") cascade: [up2x] -> sinc -> [down2x].
+ * A workgroup owns one channel of one stream and a tile of 16 equal segments
+ * per buffer; segment c of every buffer covers the same stretch of time, and
+ * segments are whole numbers of periods of the rate ratio apart, so that all
+ * 16 see the same fractional phases.  Segment 0 is warm-up (its lookback is
+ * not available), segments 1..15 produce the tile's output. */
+typedef struct Drb_Fast_Chain
+{
+    int usable;
+    int channels, sample_type, layout, history;
+    int has_up, up_taps, up_table;          /* half-band in front of the sinc stage   */
+    int has_down, down_taps, down_table;    /* half-band behind it                    */
+    int sinc_taps, sinc_cubic, sinc_table, sinc_pull;
+    int delay_place;                        /* 0 none, 1 behind the sinc stage, 2 in front of it */
+    int period_in, period_out;              /* source / target frames of the sinc stage per period */
+    int periods;                            /* periods per segment                    */
+    int blocks;                             /* 16-row blocks per period               */
+    int ksteps;                             /* 4-tap steps of a sinc row block        */
+    int seg_x, seg_u, seg_s, seg_y;         /* segment lengths: source, sinc in, sinc out, target */
+    int look_x, look_u, look_d;             /* lookback rows kept in front of a segment */
+    int off_x, off_u, off_d_odd, off_d_even, off_bank; /* LDS float offsets             */
+    int lds_floats;
+    int tile_frames;                        /* target frames per tile = 15 * seg_y    */
+    long long source_delta, target_delta;
+    double scale;
+}
+Drb_Fast_Chain;
+
 /* All functions return 0 on success, else a HIP error code. */
 int drb_hip_device_count (int * count);
 int drb_hip_get_device (int * device);
@@ -83,6 +111,16 @@ int drb_hip_launch_cascade
         float const * history,
         long long source_channel_stride, long long target_channel_stride,
         int lds_bytes, int * fault_flag, void * stream
+    );
+
+/* Matrix-core cascade: grid = stream_count x channels x max_tiles. */
+int drb_hip_launch_fast
+    (
+        Drb_Fast_Chain const * chain,
+        Drb_Device_Call const * calls, int stream_count, int max_tiles,
+        float const * history,
+        long long source_channel_stride, long long target_channel_stride,
+        int * fault_flag, void * stream
     );
 
 /* Writes every stream's new look-back (the last `history` source frames seen

@@ -7,6 +7,7 @@
  * fills in unknown (zero) fields of its two edges from the known ones.
  */
 #include "drb_plan.h"
+#include "drb_hip.h"
 
 #include <string.h>
 
@@ -580,4 +581,158 @@ void drb_plan_geometry (Drb_Plan const * plan, int lds_budget_bytes, Drb_Geometr
 
         if (geometry->lds_bytes <= lds_budget_bytes) break;
     }
+}
+
+/* ---- matrix-core geometry -------------------------------------------------- */
+
+static long long gcd_ll (long long a, long long b)
+{
+    while (b) { long long const t = a % b; a = b; b = t; }
+    return a;
+}
+
+static int half_band_table (int order)
+{
+    switch (order)
+    {
+      case 16: return 0;
+      case 32: return 8;
+      case 48: return 24;
+      case 64: return 48;
+      case 80: return 80;
+      default: return 120;
+    }
+}
+
+int drb_plan_fast_geometry (Drb_Plan const * plan, int lds_budget_bytes, Drb_Fast_Chain * chain)
+{
+    memset(chain, 0, sizeof(*chain));
+
+    /* shape: at most one 2x stage on either side of a fractional stage */
+    int up = -1, down = -1, sinc = -1, delay = -1;
+
+    for (int k = 0; k < plan->stage_count; k++)
+    {
+        switch (plan->stages[k].kind)
+        {
+          case drb_stage_up2x: if (up >= 0 || sinc >= 0) return 0; up = k; break;
+          case drb_stage_down2x: if (down >= 0 || sinc < 0) return 0; down = k; break;
+          case drb_stage_sinc: sinc = k; break;
+          case drb_stage_delay: delay = k; break;
+        }
+    }
+
+    if (sinc < 0) return 0;
+    if (delay >= 0 && delay != sinc + 1 && delay != sinc - 1) return 0;
+
+    Drb_Stage const * const stage = &plan->stages[sinc];
+    long long const g = gcd_ll(stage->in_rate, stage->out_rate);
+    long long const ratio_in = stage->in_rate / g, ratio_out = stage->out_rate / g;
+
+    /* period: a multiple of the exact rate ratio with at least 128 target frames */
+    int multiple = 1;
+
+    while (ratio_out * multiple < 128) multiple++;
+
+    int const period_out = (int)(ratio_out * multiple), period_in = (int)(ratio_in * multiple);
+
+    /* segment: whole periods, about 320 target frames, halvable where a 2x stage follows */
+    int periods = (320 + period_out / 2) / period_out;
+
+    if (periods < 1) periods = 1;
+
+    while ((up >= 0 && (periods * period_in) % 2) || (down >= 0 && (periods * period_out) % 2)) periods++;
+
+    int const taps = stage->arg % 100;
+
+    chain->channels = plan->channels;
+    chain->has_up = up >= 0;
+    chain->up_taps = up >= 0 ? plan->stages[up].arg / 2 : 0;
+    chain->up_table = up >= 0 ? half_band_table(plan->stages[up].arg) : 0;
+    chain->has_down = down >= 0;
+    chain->down_taps = down >= 0 ? plan->stages[down].arg / 2 : 0;
+    chain->down_table = down >= 0 ? half_band_table(plan->stages[down].arg) : 0;
+    chain->sinc_taps = taps;
+    chain->sinc_cubic = stage->arg >= 100;
+    chain->sinc_table = stage->arg == 16 ? 168 : stage->arg == 32 ? 1192 : stage->arg == 116 ? 3240 : 3752;
+    chain->sinc_pull = plan->direction == 1;
+    chain->delay_place = delay < 0 ? 0 : delay == sinc + 1 ? 1 : 2;
+    chain->period_in = period_in;
+    chain->period_out = period_out;
+    chain->periods = periods;
+    chain->blocks = (period_out + 15) / 16;
+    chain->source_delta = plan->source_delta;
+    chain->target_delta = plan->target_delta;
+    chain->scale = 1.0 / (double)plan->source_delta;
+
+    /* a 16-row block spans ceil(15 in/out) + 1 source frames of window ends,
+     * plus the taps, plus one for the even alignment of the window start */
+    int const spread = (int)((15 * ratio_in + ratio_out - 1) / ratio_out) + 1;
+
+    chain->ksteps = (spread + taps + 1 + 3) / 4;
+
+    if (chain->ksteps > 16) return 0;
+
+    chain->seg_u = periods * period_in;
+    chain->seg_s = periods * period_out;
+    chain->seg_x = up >= 0 ? chain->seg_u / 2 : chain->seg_u;
+    chain->seg_y = down >= 0 ? chain->seg_s / 2 : chain->seg_s;
+    /* window ends of a segment's rows run from -2 to seg_u - 1 */
+    chain->look_u = taps + 4;
+    chain->look_d = down >= 0 ? chain->down_taps : 0;
+
+    /* the up-sampler reaches back N source frames; the copy of the source into
+     * the even slots of the sinc input reaches back (look_u + N) / 2 */
+    chain->look_x = chain->look_u;
+
+    if (up >= 0)
+    {
+        int const copy_reach = (chain->look_u + chain->up_taps) / 2 + 2;
+
+        chain->look_x = ((chain->up_taps > copy_reach ? chain->up_taps : copy_reach) + 1) & ~1;
+    }
+
+    /* the fixed-point accumulator is not exactly periodic: all 16 segments use
+     * the phases of the middle one, which is off by at most this much (in
+     * source frames of the sinc stage) at the outermost segments */
+    double const exact = (double)plan->source_delta * (double)ratio_in / (double)ratio_out;
+    double const drift = ((double)plan->target_delta - exact) / (double)plan->source_delta;
+    double const worst = 7.5 * chain->seg_s * (drift < 0 ? -drift : drift);
+
+    if (worst > 1.0e-7) return 0;
+
+    int offset = 0;
+
+    if (up >= 0)
+    {
+        chain->off_x = offset;
+        offset += (chain->seg_x + chain->look_x) * 16;
+    }
+
+    chain->off_u = offset;
+    offset += (chain->seg_u + chain->look_u) * 16;
+
+    if (!chain->has_up) chain->off_x = chain->off_u;
+
+    if (down >= 0)
+    {
+        chain->off_d_odd = offset;
+        offset += (chain->seg_s / 2 + chain->look_d) * 16;
+        chain->off_d_even = offset;
+        offset += (chain->seg_s / 2 + chain->look_d) * 16;
+    }
+
+    chain->off_bank = offset;
+    offset += (chain->sinc_cubic ? 32 : 64) * (taps + 1);
+    chain->lds_floats = offset + 32;
+
+    if (chain->lds_floats * 4 > lds_budget_bytes) return 0;
+
+    chain->tile_frames = 15 * chain->seg_y;
+    chain->usable = 1;
+
+    /* warm-up segment plus its own lookback, seen from the first target frame */
+    int const reach = chain->seg_x + chain->look_x + (up >= 0 ? chain->up_taps : 0) + taps + 8;
+
+    return (reach + 3) / 4 * 4;
 }

@@ -117,6 +117,14 @@ Drb_Geometry;
 
 void drb_plan_geometry (Drb_Plan const * plan, int lds_budget_bytes, Drb_Geometry * geometry);
 
+struct Drb_Fast_Chain;
+
+/* Fills the matrix-core geometry for plans of the shape [up2x] sinc [down2x]
+ * whose fixed-point phase drift over a tile stays below the accuracy budget;
+ * chain->usable is 0 otherwise.  Returns the source frames of history the
+ * fast kernel wants (0 if unusable). */
+int drb_plan_fast_geometry (Drb_Plan const * plan, int lds_budget_bytes, struct Drb_Fast_Chain * chain);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,7 +49,8 @@ class PlanInfo(ctypes.Structure):
                 ("buffer_length", ctypes.c_long), ("converter_size", ctypes.c_long),
                 ("history_frames", ctypes.c_int), ("tile_frames", ctypes.c_int),
                 ("flops_per_output_sample", ctypes.c_double),
-                ("bytes_per_output_sample", ctypes.c_double)]
+                ("bytes_per_output_sample", ctypes.c_double),
+                ("fast_path", ctypes.c_int), ("fast_tile_frames", ctypes.c_int)]
 
     def stages(self):
         kinds = {1: "up2x", 2: "down2x", 3: "sinc", 4: "slicer"}

@@ -297,6 +297,9 @@ typedef struct DrbAmd_Plan_Info
     int tile_frames;        /* target frames per workgroup tile                    */
     double flops_per_output_sample;  /* upstream cascade as written, 2 x MACs      */
     double bytes_per_output_sample;  /* source + target bytes per target sample     */
+    int fast_path;          /* 1: fast arithmetic runs the matrix-core kernel,
+                               0: it runs the same kernel as exact arithmetic      */
+    int fast_tile_frames;   /* target frames per workgroup tile of that kernel      */
 }
 DrbAmd_Plan_Info;
 
