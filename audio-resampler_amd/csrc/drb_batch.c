@@ -202,7 +202,7 @@ DrbAmd_Status drb_amd_plan_info (DrbAmd_Batch_Config const * config, DrbAmd_Plan
     Drb_Fast_Chain fast;
 
     drb_plan_fast_geometry(&plan, fast_lds_budget, &fast);
-    info->fast_path = fast.usable;
+    info->fast_path = fast.usable && drb_hip_fast_kernel_exists(&fast);
     info->fast_tile_frames = fast.tile_frames;
 
     return drb_amd_ok;
@@ -319,9 +319,16 @@ DrbAmd_Status drb_amd_batch_create (DrbAmd_Batch_Config const * config, DrbAmd_B
     build_chain(config, &plan, &batch->geometry, &batch->chain);
 
     drb_plan_fast_geometry(&plan, fast_lds_budget, &batch->fast);
+
+    if (batch->fast.usable && !drb_hip_fast_kernel_exists(&batch->fast)) batch->fast.usable = 0;
+
     batch->fast.sample_type = config->sample_type;
     batch->fast.layout = config->layout;
     batch->fast.history = batch->geometry.history_frames;
+
+    /* timing diagnostics only: skip phases of the fast kernel (results are wrong) */
+    char const * const ablate = getenv("DRB_AMD_FAST_ABLATE");
+    batch->fast.ablate = ablate ? atoi(ablate) : 0;
 
     size_t const n = (size_t)config->stream_count;
 

@@ -63,6 +63,7 @@ Drb_Device_Call;
 typedef struct Drb_Fast_Chain
 {
     int usable;
+    int ablate;                             /* diagnostic: bit mask of phases to skip (timing only) */
     int channels, sample_type, layout, history;
     int has_up, up_taps, up_table;          /* half-band in front of the sinc stage   */
     int has_down, down_taps, down_table;    /* half-band behind it                    */
@@ -73,8 +74,11 @@ typedef struct Drb_Fast_Chain
     int blocks;                             /* 16-row blocks per period               */
     int ksteps;                             /* 4-tap steps of a sinc row block        */
     int seg_x, seg_u, seg_s, seg_y;         /* segment lengths: source, sinc in, sinc out, target */
-    int look_x, look_u, look_d;             /* lookback rows kept in front of a segment */
+    int look_x, look_u, look_d;             /* lookback rows kept in front of a segment:
+                                               source, sinc input (odd plane when an
+                                               up-sampler feeds it), planes of d      */
     int off_x, off_u, off_d_odd, off_d_even, off_bank; /* LDS float offsets             */
+    int types_per_wave;                     /* row-block types one wave keeps coefficients for */
     int lds_floats;
     int tile_frames;                        /* target frames per tile = 15 * seg_y    */
     long long source_delta, target_delta;
@@ -112,6 +116,9 @@ int drb_hip_launch_cascade
         long long source_channel_stride, long long target_channel_stride,
         int lds_bytes, int * fault_flag, void * stream
     );
+
+/* 1 if a kernel image was built for this chain's filter lengths. */
+int drb_hip_fast_kernel_exists (Drb_Fast_Chain const * chain);
 
 /* Matrix-core cascade: grid = stream_count x channels x max_tiles. */
 int drb_hip_launch_fast

@@ -677,19 +677,25 @@ int drb_plan_fast_geometry (Drb_Plan const * plan, int lds_budget_bytes, Drb_Fas
     chain->seg_s = periods * period_out;
     chain->seg_x = up >= 0 ? chain->seg_u / 2 : chain->seg_u;
     chain->seg_y = down >= 0 ? chain->seg_s / 2 : chain->seg_s;
-    /* window ends of a segment's rows run from -2 to seg_u - 1 */
-    chain->look_u = taps + 4;
+    /* Window ends of a segment's rows run from -2 to seg_u - 1, so the sinc
+     * stage reaches back taps + 4 of its input rows.  Behind an up-sampler its
+     * input lives in two planes indexed by source row: the source itself
+     * (even samples, u[2 f] = x[f - N / 2]) and the up-sampler's output (odd
+     * samples); look_u then counts rows of the odd plane. */
     chain->look_d = down >= 0 ? chain->down_taps : 0;
-
-    /* the up-sampler reaches back N source frames; the copy of the source into
-     * the even slots of the sinc input reaches back (look_u + N) / 2 */
-    chain->look_x = chain->look_u;
 
     if (up >= 0)
     {
-        int const copy_reach = (chain->look_u + chain->up_taps) / 2 + 2;
+        int const reach = (taps + 4) / 2 + 2;
+        int const even_reach = reach + chain->up_taps / 2;
 
-        chain->look_x = ((chain->up_taps > copy_reach ? chain->up_taps : copy_reach) + 1) & ~1;
+        chain->look_u = (reach + 1) & ~1;
+        chain->look_x = ((chain->up_taps > even_reach ? chain->up_taps : even_reach) + 1) & ~1;
+    }
+    else
+    {
+        chain->look_u = taps + 4;
+        chain->look_x = chain->look_u;
     }
 
     /* the fixed-point accumulator is not exactly periodic: all 16 segments use
@@ -701,18 +707,28 @@ int drb_plan_fast_geometry (Drb_Plan const * plan, int lds_budget_bytes, Drb_Fas
 
     if (worst > 1.0e-7) return 0;
 
+    /* LDS map.  Every buffer is [row][16 segments]; a row is 16 floats, so
+     * consecutive rows alternate between the two halves of the 32 banks.  In
+     * the sinc stage one half of a wave's lanes reads the source plane and the
+     * other half the odd plane, at rows of equal parity: the odd plane is
+     * placed an odd number of rows away so that the two never share banks. */
     int offset = 0;
+
+    chain->off_x = offset;
+    offset += (chain->seg_x + chain->look_x) * 16;
 
     if (up >= 0)
     {
-        chain->off_x = offset;
-        offset += (chain->seg_x + chain->look_x) * 16;
+        /* rows read together: source row t - N / 2 + look_x and odd row t + look_u */
+        if (((chain->up_taps / 2 + chain->look_x + chain->look_u + offset / 16) & 1) == 0) offset += 16;
+
+        chain->off_u = offset;
+        offset += (chain->seg_x + chain->look_u) * 16;
     }
-
-    chain->off_u = offset;
-    offset += (chain->seg_u + chain->look_u) * 16;
-
-    if (!chain->has_up) chain->off_x = chain->off_u;
+    else
+    {
+        chain->off_u = chain->off_x;
+    }
 
     if (down >= 0)
     {
@@ -723,10 +739,21 @@ int drb_plan_fast_geometry (Drb_Plan const * plan, int lds_budget_bytes, Drb_Fas
     }
 
     chain->off_bank = offset;
-    offset += (chain->sinc_cubic ? 32 : 64) * (taps + 1);
+    offset += taps * 65 + 8; /* the bank as [tap][row], 65 floats between taps */
+    offset += 64 * ((chain->up_taps + 16) / 4 + (chain->down_taps + 16) / 4); /* half-band coefficient fragments */
     chain->lds_floats = offset + 32;
 
     if (chain->lds_floats * 4 > lds_budget_bytes) return 0;
+
+    /* row blocks of the sinc stage are dealt to the four waves in runs */
+    {
+        int const chains = chain->blocks * chain->periods;
+        int const share = (chains + 3) / 4;
+
+        chain->types_per_wave = (share + chain->periods - 2) / chain->periods + 1;
+
+        if (chain->types_per_wave > 3) return 0;
+    }
 
     chain->tile_frames = 15 * chain->seg_y;
     chain->usable = 1;
