@@ -19,7 +19,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-enum { ring_slots = 4, max_step_frames = 1 << 24 };
+enum { ring_slots = 4, max_step_frames = 1 << 24, fault_words = 128 };
 
 struct DrbAmd_Batch
 {
@@ -353,7 +353,7 @@ DrbAmd_Status drb_amd_batch_create (DrbAmd_Batch_Config const * config, DrbAmd_B
     code = drb_hip_alloc((void **)&batch->history[0], history_bytes);
     if (!code) code = drb_hip_alloc((void **)&batch->history[1], history_bytes);
     if (!code) code = drb_hip_alloc((void **)&batch->calls_device, n * sizeof(Drb_Device_Call));
-    if (!code) code = drb_hip_alloc((void **)&batch->fault_device, sizeof(int));
+    if (!code) code = drb_hip_alloc((void **)&batch->fault_device, fault_words * sizeof(long long));
     if (!code) code = drb_hip_host_alloc((void **)&batch->fault_host, sizeof(int));
 
     for (int i = 0; i < ring_slots && !code; i++)
@@ -362,7 +362,7 @@ DrbAmd_Status drb_amd_batch_create (DrbAmd_Batch_Config const * config, DrbAmd_B
         if (!code) code = drb_hip_event_create(&batch->slot_done[i]);
     }
 
-    if (!code) code = drb_hip_memset_async(batch->fault_device, 0, sizeof(int), 0);
+    if (!code) code = drb_hip_memset_async(batch->fault_device, 0, fault_words * sizeof(long long), 0);
 
     if (code)
     {
@@ -656,3 +656,21 @@ DrbAmd_Status drb_amd_batch_kernel_ms (DrbAmd_Batch * batch, float * millisecond
 
     return drb_amd_ok;
 }
+
+#ifdef DRB_FAST_STAMPS
+/* Diagnostic build only: the cycle counters the stamped fast kernel sums up
+ * behind the fault word (see drb_kernels_fast.hip). */
+DrbAmd_Status drb_amd_debug_counters (DrbAmd_Batch * batch, unsigned long long * counters, int count)
+{
+    if (!batch || count > fault_words - 1) return fail(drb_amd_error_bad_argument, "bad argument");
+
+    int code = drb_hip_set_device(batch->device);
+
+    if (!code) code = drb_hip_stream_synchronize(0);
+    if (!code) code = drb_hip_download_async(counters, (char *)batch->fault_device + 8, (size_t)count * 8, 0);
+    if (!code) code = drb_hip_stream_synchronize(0);
+    if (!code) code = drb_hip_memset_async((char *)batch->fault_device + 8, 0, (size_t)count * 8, 0);
+
+    return code ? fail_hip("debug counters", code) : drb_amd_ok;
+}
+#endif

@@ -128,7 +128,9 @@ __device__ __forceinline__ void store_sample (unsigned long long base, long long
 }
 
 // Source frame of one channel; negative frames come from the stream's history,
-// anything older is silence.
+// anything older is silence.  PLAIN = planar float32 buffers (known at compile
+// time so that the common case carries no sample-type or layout code).
+template <bool PLAIN>
 __device__ __forceinline__ float source_frame
     (
         Drb_Fast_Chain const & chain, Drb_Device_Call const & call,
@@ -142,11 +144,33 @@ __device__ __forceinline__ float source_frame
 
     if (frame >= call.source_frames) return 0.0f;
 
+    if (PLAIN) return global_pointer<float const>(call.source)[channel * channel_stride + frame];
+
     long long const index = chain.layout == kInterleaved
         ? static_cast<long long>(frame) * chain.channels + channel
         : channel * channel_stride + frame;
 
     return load_sample(call.source, index, chain.sample_type);
+}
+
+template <bool PLAIN>
+__device__ __forceinline__ void target_frame
+    (
+        Drb_Fast_Chain const & chain, Drb_Device_Call const & call,
+        long long channel_stride, int channel, int frame, float value
+    )
+{
+    if (PLAIN)
+    {
+        global_pointer<float>(call.target)[channel * channel_stride + frame] = value;
+        return;
+    }
+
+    long long const index = chain.layout == kInterleaved
+        ? static_cast<long long>(frame) * chain.channels + channel
+        : channel * channel_stride + frame;
+
+    store_sample(call.target, index, chain.sample_type, value);
 }
 
 // Source frames consumed before the output with accumulator value `phase`, and
@@ -380,6 +404,7 @@ __device__ __forceinline__ void build_sinc_type
     type.first_row = first_row;
 }
 
+template <bool DOWN, bool PLAIN>
 __device__ __forceinline__ void write_sinc
     (
         Drb_Fast_Chain const & chain, Drb_Device_Call const & call, Tile const & tile, Buffers const & buf,
@@ -387,18 +412,20 @@ __device__ __forceinline__ void write_sinc
     )
 {
     int const lane = threadIdx.x & 63, column = lane & 15, quad = lane >> 4;
+    int const in_period = 16 * block + 4 * quad;
+    int const t0 = period * chain.period_out + in_period;   // row of the sinc output = row of d
 
-    #pragma unroll
-    for (int r = 0; r < 4; r++)
+    if (DOWN)
     {
-        int const in_period = 16 * block + 4 * quad + r;
-        int const t = period * chain.period_out + in_period;   // row of the sinc output = row of d
+        // rows alternate between the planes of d; a period may start on either
+        int const half = chain.seg_s >> 1;
 
-        if (in_period >= chain.period_out) continue;
-
-        if (chain.has_down)
+        #pragma unroll
+        for (int r = 0; r < 4; r++)
         {
-            int const g = t >> 1, half = chain.seg_s >> 1;
+            int const t = t0 + r, g = t >> 1;
+
+            if (in_period + r >= chain.period_out) continue;
 
             if (t & 1)
             {
@@ -413,17 +440,17 @@ __device__ __forceinline__ void write_sinc
                 if (g >= half - chain.look_d && column < 15) buf.d_even[cell_centre(g - half + chain.look_d, column + 1)] = acc[r];
             }
         }
-        else
+    }
+    else
+    {
+        #pragma unroll
+        for (int r = 0; r < 4; r++)
         {
-            int const frame = tile.base_y + column * chain.seg_y + t;
+            int const frame = tile.base_y + column * chain.seg_y + t0 + r;
 
-            if (column >= 1 && frame < call.target_frames)
+            if (in_period + r < chain.period_out && column >= 1 && frame < call.target_frames)
             {
-                long long const index = chain.layout == kInterleaved
-                    ? static_cast<long long>(frame) * chain.channels + channel
-                    : channel * target_channel_stride + frame;
-
-                store_sample(call.target, index, chain.sample_type, acc[r]);
+                target_frame<PLAIN>(chain, call, target_channel_stride, channel, frame, acc[r]);
             }
         }
     }
@@ -445,12 +472,12 @@ __device__ __forceinline__ float const * sinc_operand (Drb_Fast_Chain const & ch
                    : buf.x + cell(((u - chain.up_taps) >> 1) + chain.look_x, column);
 }
 
-template <int STEPS, bool PLANES>
+template <int STEPS, bool PLANES, bool DOWN, bool PLAIN>
 __device__ __forceinline__ void stage_sinc
     (
         Drb_Fast_Chain const & chain, Drb_Device_Call const & call, Tile const & tile, Buffers const & buf,
         int channel, long long target_channel_stride,
-        Sinc_Type<STEPS> (& types) [kMaxTypes], float drift
+        Sinc_Type<STEPS> const (& types) [kMaxTypes], float drift
     )
 {
     constexpr int kStride = PLANES ? 32 : 64;
@@ -461,48 +488,54 @@ __device__ __forceinline__ void stage_sinc
     int const first = wave * share, last = min(first + share, chains);
     int const first_block = first / chain.periods;
 
-    #pragma unroll
-    for (int i = 0; i < kMaxTypes; i++)
+    // One copy of the code for all of the wave's row blocks: the block's
+    // coefficient set is picked out of the (statically indexed) registers.
+    for (int q = first; q < last; )
     {
-        int const block = first_block + i;
-        int const low = max(first, block * chain.periods), high = min(last, (block + 1) * chain.periods);
+        int const block = q / chain.periods, period = q - block * chain.periods;
+        int const slot = block - first_block;
+        bool const pair = period + 1 < chain.periods && q + 1 < last;
 
-        if (low >= high) continue;
-
-        // coefficients at this tile's phase
         float a [STEPS];
+        int first_row = period * chain.period_in;
 
+        // coefficients at this tile's phase; the slot is uniform over the wave
         #pragma unroll
-        for (int s = 0; s < STEPS; s++) a[s] = fmaf(drift, types[i].g[s], types[i].a[s]);
-
-        int q = low;
-
-        for (; q + 1 < high; q += 2)
+        for (int i = 0; i < kMaxTypes; i++)
         {
-            int const period = q - block * chain.periods;
-            float b0 [STEPS], b1 [STEPS];
-            float4_t acc0, acc1;
+            if (__builtin_amdgcn_readfirstlane(slot) == i)
+            {
+                #pragma unroll
+                for (int s = 0; s < STEPS; s++) a[s] = fmaf(drift, types[i].g[s], types[i].a[s]);
 
-            load_rows<STEPS, kStride>(sinc_operand<PLANES>(chain, buf, types[i].first_row + period * chain.period_in), b0);
-            load_rows<STEPS, kStride>(sinc_operand<PLANES>(chain, buf, types[i].first_row + (period + 1) * chain.period_in), b1);
-            multiply_pair<STEPS>(a, b0, b1, acc0, acc1);
-            write_sinc(chain, call, tile, buf, channel, target_channel_stride, block, period, acc0);
-            write_sinc(chain, call, tile, buf, channel, target_channel_stride, block, period + 1, acc1);
+                first_row += types[i].first_row;
+            }
         }
 
-        if (q < high)
-        {
-            int const period = q - block * chain.periods;
-            float b0 [STEPS];
+        float b0 [STEPS], b1 [STEPS];
+        float4_t acc0, acc1;
 
-            load_rows<STEPS, kStride>(sinc_operand<PLANES>(chain, buf, types[i].first_row + period * chain.period_in), b0);
-            write_sinc(chain, call, tile, buf, channel, target_channel_stride, block, period, multiply<STEPS>(a, b0));
+        load_rows<STEPS, kStride>(sinc_operand<PLANES>(chain, buf, first_row), b0);
+
+        if (pair)
+        {
+            load_rows<STEPS, kStride>(sinc_operand<PLANES>(chain, buf, first_row + chain.period_in), b1);
+            multiply_pair<STEPS>(a, b0, b1, acc0, acc1);
+            write_sinc<DOWN, PLAIN>(chain, call, tile, buf, channel, target_channel_stride, block, period, acc0);
+            write_sinc<DOWN, PLAIN>(chain, call, tile, buf, channel, target_channel_stride, block, period + 1, acc1);
+            q += 2;
+        }
+        else
+        {
+            write_sinc<DOWN, PLAIN>(chain, call, tile, buf, channel, target_channel_stride, block, period, multiply<STEPS>(a, b0));
+            q += 1;
         }
     }
 }
 
 // ---- down-sampler --------------------------------------------------------------------
 // y[f] = 0.5 d[2 f - N] + sum_j h[j] d[2 (f - N + j) + 1]
+template <bool PLAIN>
 __device__ __forceinline__ void write_down
     (
         Drb_Fast_Chain const & chain, Drb_Device_Call const & call, Tile const & tile, Buffers const & buf,
@@ -523,8 +556,7 @@ __device__ __forceinline__ void write_down
 
     if (column < 1) return;
 
-    if (chain.sample_type == kSampleF32 && chain.layout == kPlanar
-        && t0 + 3 < chain.seg_y && frame0 + 3 < call.target_frames)
+    if (PLAIN && t0 + 3 < chain.seg_y && frame0 + 3 < call.target_frames)
     {
         DRB_GLOBAL float * const out = global_pointer<float>(call.target) + channel * target_channel_stride + frame0;
         *reinterpret_cast<DRB_GLOBAL float4_unaligned *>(out) = float4_unaligned{ value[0], value[1], value[2], value[3] };
@@ -534,20 +566,14 @@ __device__ __forceinline__ void write_down
     #pragma unroll
     for (int r = 0; r < 4; r++)
     {
-        int const frame = frame0 + r;
-
-        if (t0 + r < chain.seg_y && frame < call.target_frames)
+        if (t0 + r < chain.seg_y && frame0 + r < call.target_frames)
         {
-            long long const index = chain.layout == kInterleaved
-                ? static_cast<long long>(frame) * chain.channels + channel
-                : channel * target_channel_stride + frame;
-
-            store_sample(call.target, index, chain.sample_type, value[r]);
+            target_frame<PLAIN>(chain, call, target_channel_stride, channel, frame0 + r, value[r]);
         }
     }
 }
 
-template <int STEPS>
+template <int STEPS, bool PLAIN>
 __device__ __forceinline__ void stage_down
     (
         Drb_Fast_Chain const & chain, Drb_Device_Call const & call, Tile const & tile, Buffers const & buf,
@@ -568,8 +594,8 @@ __device__ __forceinline__ void stage_down
         load_rows<STEPS, 64>(origin + 256 * block, b0);
         load_rows<STEPS, 64>(origin + 256 * (block + kWaves), b1);
         multiply_pair<STEPS>(a, b0, b1, acc0, acc1);
-        write_down(chain, call, tile, buf, channel, target_channel_stride, block, acc0);
-        write_down(chain, call, tile, buf, channel, target_channel_stride, block + kWaves, acc1);
+        write_down<PLAIN>(chain, call, tile, buf, channel, target_channel_stride, block, acc0);
+        write_down<PLAIN>(chain, call, tile, buf, channel, target_channel_stride, block + kWaves, acc1);
     }
 
     if (block < blocks)
@@ -577,7 +603,7 @@ __device__ __forceinline__ void stage_down
         float b0 [STEPS];
 
         load_rows<STEPS, 64>(origin + 256 * block, b0);
-        write_down(chain, call, tile, buf, channel, target_channel_stride, block, multiply<STEPS>(a, b0));
+        write_down<PLAIN>(chain, call, tile, buf, channel, target_channel_stride, block, multiply<STEPS>(a, b0));
     }
 }
 
@@ -591,6 +617,7 @@ struct Fetch
 };
 
 // Thread t holds rows 4 (t >> 4) + 64 i + {0..3} of segment t & 15.
+template <bool PLAIN>
 __device__ __forceinline__ void fetch_tile
     (
         Drb_Fast_Chain const & chain, Drb_Device_Call const & call, int base_x,
@@ -603,7 +630,7 @@ __device__ __forceinline__ void fetch_tile
 
     // Interior tiles of planar float streams (the common case, decided for the
     // whole workgroup): every row is a plain dwordx4 load and nothing waits.
-    bool const interior = chain.sample_type == kSampleF32 && chain.layout == kPlanar
+    bool const interior = PLAIN
         && base_x - chain.look_x >= 0
         && base_x + 15 * chain.seg_x + ((rows + 3) & ~3) + 64 <= call.source_frames;
 
@@ -633,7 +660,7 @@ __device__ __forceinline__ void fetch_tile
             #pragma unroll
             for (int e = 0; e < 4; e++)
             {
-                fetch.v[i][e] = source_frame(chain, call, history, source_channel_stride, channel,
+                fetch.v[i][e] = source_frame<PLAIN>(chain, call, history, source_channel_stride, channel,
                                              first_frame + 64 * i + e);
             }
         }
@@ -658,7 +685,16 @@ __device__ __forceinline__ void store_tile (Drb_Fast_Chain const & chain, Buffer
     }
 }
 
-template <int UP_STEPS, int SINC_STEPS, int DOWN_STEPS>
+// Diagnostic build only (-DDRB_FAST_STAMPS): where a wave's cycles go, summed
+// per phase into fault_flag[1 + 16 wave_class + phase] (the flag word itself is
+// word 0).  Never compiled into the library that ships.
+#ifdef DRB_FAST_STAMPS
+#  define STAMP(phase) do { long long const now_ = __builtin_readcyclecounter(); spent[phase] += now_ - mark; mark = now_; } while (0)
+#else
+#  define STAMP(phase) do { } while (0)
+#endif
+
+template <int UP_STEPS, int SINC_STEPS, int DOWN_STEPS, bool PLAIN>
 __global__ __launch_bounds__(kThreads, 2) void drb_fast_kernel
     (
         Drb_Fast_Chain const chain,
@@ -724,6 +760,11 @@ __global__ __launch_bounds__(kThreads, 2) void drb_fast_kernel
     int const delay_front = chain.delay_place == 2 ? call.delay : 0;
     int const tile_advance_s = (DOWN_STEPS ? 2 : 1) * chain.tile_frames;   // sinc outputs per tile
 
+#ifdef DRB_FAST_STAMPS
+    long long spent [10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    long long mark = __builtin_readcyclecounter();
+#endif
+
     Sinc_Type<SINC_STEPS> types [kMaxTypes];
     Sinc_Anchor anchor = { 0, 0, 0, 0 };
     int since_build = kRebuild;
@@ -785,12 +826,18 @@ __global__ __launch_bounds__(kThreads, 2) void drb_fast_kernel
 
         if (!fetched && !(chain.ablate & 1))
         {
-            fetch_tile(chain, call, tile.base_x, stream_history, source_channel_stride, channel, fetch);
+            fetch_tile<PLAIN>(chain, call, tile.base_x, stream_history, source_channel_stride, channel, fetch);
         }
+
+        STAMP(0);
 
         if (!(chain.ablate & 1)) store_tile(chain, buf, fetch);
 
+        STAMP(1);
+
         __syncthreads();   // source tile (and bank) in place
+
+        STAMP(2);
 
         // the next tile's source travels while this one is filtered
         {
@@ -800,10 +847,12 @@ __global__ __launch_bounds__(kThreads, 2) void drb_fast_kernel
 
             if (fetched && !(chain.ablate & 1))
             {
-                fetch_tile(chain, call, tile.base_x + tile_stride * 15 * chain.seg_x, stream_history,
+                fetch_tile<PLAIN>(chain, call, tile.base_x + tile_stride * 15 * chain.seg_x, stream_history,
                            source_channel_stride, channel, fetch);
             }
         }
+
+        STAMP(3);
 
         if (rebuild && !(chain.ablate & 4))
         {
@@ -821,6 +870,8 @@ __global__ __launch_bounds__(kThreads, 2) void drb_fast_kernel
             }
         }
 
+        STAMP(4);
+
         if (UP_STEPS > 0)
         {
             if (!(chain.ablate & 2))
@@ -831,24 +882,45 @@ __global__ __launch_bounds__(kThreads, 2) void drb_fast_kernel
                 stage_up<UP_STEPS ? UP_STEPS : 1>(chain, buf, a_up);
             }
 
+            STAMP(5);
+
             __syncthreads();   // odd plane of the sinc input complete
+
+            STAMP(6);
         }
 
         if (!(chain.ablate & 4))
         {
-            stage_sinc<SINC_STEPS, (UP_STEPS > 0)>(chain, call, tile, buf, channel, target_channel_stride, types, drift);
+            stage_sinc<SINC_STEPS, (UP_STEPS > 0), (DOWN_STEPS > 0), PLAIN>(chain, call, tile, buf, channel, target_channel_stride, types, drift);
         }
 
+        STAMP(7);
+
         __syncthreads();   // both planes of d complete; source plane free again
+
+        STAMP(8);
 
         if (DOWN_STEPS > 0 && !(chain.ablate & 8))
         {
             float a_down [DOWN_STEPS ? DOWN_STEPS : 1];
 
             load_rows<DOWN_STEPS ? DOWN_STEPS : 1, 64>(park_down + lane, a_down);
-            stage_down<DOWN_STEPS ? DOWN_STEPS : 1>(chain, call, tile, buf, channel, target_channel_stride, a_down);
+            stage_down<DOWN_STEPS ? DOWN_STEPS : 1, PLAIN>(chain, call, tile, buf, channel, target_channel_stride, a_down);
+        }
+
+        STAMP(9);
+    }
+
+#ifdef DRB_FAST_STAMPS
+    if (lane == 0)
+    {
+        for (int phase = 0; phase < 10; phase++)
+        {
+            atomicAdd(reinterpret_cast<unsigned long long *>(fault_flag) + 1 + 16 * wave + phase,
+                      static_cast<unsigned long long>(spent[phase]));
         }
     }
+#endif
 }
 
 typedef void Fast_Kernel
@@ -864,17 +936,24 @@ Fast_Kernel * pick_kernel (Drb_Fast_Chain const * chain)
     int const down = chain->has_down ? (chain->down_taps + 16) / 4 : 0;
     int const key = up * 10000 + chain->ksteps * 100 + down;
 
+    bool const plain = chain->sample_type == kSampleF32 && chain->layout == kPlanar;
+
+#define DRB_FAST_CASE(KEY, UP, SINC, DOWN) \
+      case KEY: return plain ? drb_fast_kernel<UP, SINC, DOWN, true> : drb_fast_kernel<UP, SINC, DOWN, false>;
+
     switch (key)
     {
-      case 141214: return drb_fast_kernel<14, 12, 14>;   // good, rate going up
-      case 141314: return drb_fast_kernel<14, 13, 14>;   // good, rate going down
-      case 120812: return drb_fast_kernel<12, 8, 12>;    // fine
-      case 120912: return drb_fast_kernel<12, 9, 12>;
-      case 161216: return drb_fast_kernel<16, 12, 16>;   // best
-      case 161316: return drb_fast_kernel<16, 13, 16>;
-      case 800: return drb_fast_kernel<0, 8, 0>;         // poor
-      case 900: return drb_fast_kernel<0, 9, 0>;
+      DRB_FAST_CASE(141214, 14, 12, 14)   // good, rate going up
+      DRB_FAST_CASE(141314, 14, 13, 14)   // good, rate going down
+      DRB_FAST_CASE(120812, 12, 8, 12)    // fine
+      DRB_FAST_CASE(120912, 12, 9, 12)
+      DRB_FAST_CASE(161216, 16, 12, 16)   // best
+      DRB_FAST_CASE(161316, 16, 13, 16)
+      DRB_FAST_CASE(800, 0, 8, 0)         // poor
+      DRB_FAST_CASE(900, 0, 9, 0)
     }
+
+#undef DRB_FAST_CASE
 
     return nullptr;
 }

@@ -9,7 +9,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(os.path.dirname(HERE), "lib")
-LIB_PATH = os.path.join(LIB_DIR, "libdrb_audio_converter_amd.so")
+LIB_PATH = os.environ.get("DRB_AMD_LIB") or os.path.join(LIB_DIR, "libdrb_audio_converter_amd.so")
 HARNESS_PATH = os.path.join(LIB_DIR, "libdrb_api_harness.so")
 
 PUSH, PULL = 0, 1
