@@ -77,7 +77,10 @@ typedef struct Drb_Fast_Chain
     int look_x, look_u, look_d;             /* lookback rows kept in front of a segment:
                                                source, sinc input (odd plane when an
                                                up-sampler feeds it), planes of d      */
-    int off_x, off_u, off_d_odd, off_d_even, off_bank; /* LDS float offsets             */
+    int off_x, off_u, off_d_odd, off_d_even; /* LDS float offsets                      */
+    int off_bank;                           /* sinc bank: shares the planes of d where a down-sampler exists */
+    int off_taps;                           /* half-band taps, zero-padded: up, then down */
+    int waves;                              /* waves per workgroup: 4 or 5, whichever deals the row blocks out more evenly */
     int types_per_wave;                     /* row-block types one wave keeps coefficients for */
     int lds_floats;
     int tile_frames;                        /* target frames per tile = 15 * seg_y    */

@@ -39,8 +39,7 @@
 namespace
 {
 
-constexpr int kThreads = 256;
-constexpr int kWaves = kThreads / 64;
+constexpr int kMaxThreads = 320;     // four or five waves, whichever deals the row blocks out more evenly
 constexpr int kBankRowStride = 65;
 constexpr int kMaxTypes = 3;         // row-block types a wave keeps sinc coefficients for
 constexpr int kRebuild = 16;         // tiles between exact rebuilds of those coefficients   // floats between taps in the LDS copy of the sinc bank
@@ -77,14 +76,6 @@ __device__ __forceinline__ float const * table_at (int float_offset)
 __device__ __forceinline__ int cell (int row, int column)
 {
     return (row << 4) + column;
-}
-
-// The even plane of d is read four rows apart per lane group (the
-// down-sampler's centre tap): flipping the half on bit 2 of the row keeps
-// those reads to two per bank.
-__device__ __forceinline__ int cell_centre (int row, int column)
-{
-    return ((row << 4) + column) ^ (((row >> 2) & 1) << 4);
 }
 
 __device__ __forceinline__ float load_sample (unsigned long long base, long long index, int type)
@@ -220,32 +211,17 @@ __device__ __forceinline__ float4_t multiply (float const (& a) [STEPS], float c
     return acc;
 }
 
-// Two independent row blocks with the same coefficients, interleaved so that
-// neither accumulator waits on the other.
-template <int STEPS>
-__device__ __forceinline__ void multiply_pair
-    (
-        float const (& a) [STEPS], float const (& b0) [STEPS], float const (& b1) [STEPS],
-        float4_t & acc0, float4_t & acc1
-    )
-{
-    acc0 = float4_t{ 0.0f, 0.0f, 0.0f, 0.0f };
-    acc1 = float4_t{ 0.0f, 0.0f, 0.0f, 0.0f };
-
-    #pragma unroll
-    for (int s = 0; s < STEPS; s++)
-    {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b0[s], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b1[s], acc1, 0, 0, 0);
-    }
-}
-
 struct Tile
 {
-    int base_y;   // target index of (segment 0, row 0)
-    int base_s;   // sinc-output index of (segment 0, row 0)
-    int base_u;   // sinc-input index of (segment 0, row 0)
-    int base_x;   // source index of (segment 0, row 0)
+    int index;
+    int base_y;      // target index of (segment 0, row 0)
+    int base_s;      // sinc-output index of (segment 0, row 0)
+    int base_u;      // sinc-input index of (segment 0, row 0)
+    int base_x;      // source index of (segment 0, row 0)
+    float drift;     // sub-sample position now minus at the last exact build
+    bool rebuild;    // sinc coefficients are rebuilt from the exact phase for this tile
+    bool inside;     // all 16 segments end before the stream's last target frame
+    bool fetched;    // its source rows are in registers already
 };
 
 struct Buffers
@@ -253,60 +229,75 @@ struct Buffers
     float * x, * u, * d_odd, * d_even, * bank;
 };
 
+// Float offsets of a lane inside a [row][16 segments] buffer.  Everything a
+// stage adds to them is the same for the whole wave (scalar registers) or a
+// constant of the instruction, so an access costs at most one vector add.
+struct Lane
+{
+    int column, quad;
+    int operand;        // (row quad, column): B operands, rows 4 steps apart
+    int result;         // (row 4 quad, column): the lane's four result rows
+    int planes;         // (row 2 quad, column): result rows dealt to two planes
+    int sinc_even;      // B operand of the fractional stage behind an up-sampler,
+    int sinc_odd;       //   relative to `lds`, for an even / odd first row
+};
+
 // ---- up-sampler: odd sinc-input samples ------------------------------------------
 // u[2 f + 1] = 2 sum_j h[j] x[f - N + 1 + j], stored by source row f; the even
 // ones, u[2 f] = x[f - N / 2], are read straight from the source plane.
-__device__ __forceinline__ void write_up (Drb_Fast_Chain const & chain, Buffers const & buf, int block, float4_t acc)
+__device__ __forceinline__ void write_up
+    (
+        Drb_Fast_Chain const & chain, Buffers const & buf, Lane const & lane, int block, float4_t acc
+    )
 {
-    int const lane = threadIdx.x & 63, column = lane & 15, quad = lane >> 4;
+    float * const rows = buf.u + 16 * (16 * block + chain.look_u) + lane.result;
+
+    // blocks that end before the segment's tail: four plain stores
+    if (16 * block + 16 <= chain.seg_x - chain.look_u)
+    {
+        rows[0] = acc[0];
+        rows[16] = acc[1];
+        rows[32] = acc[2];
+        rows[48] = acc[3];
+        return;
+    }
+
+    // the tail of a segment is also the lookback of the next one
+    float * const next = rows - 16 * chain.seg_x + 1;
 
     #pragma unroll
     for (int r = 0; r < 4; r++)
     {
-        int const t = 16 * block + 4 * quad + r;
+        int const t = 16 * block + 4 * lane.quad + r;
 
         if (t < chain.seg_x)
         {
-            buf.u[cell(t + chain.look_u, column)] = acc[r];
+            rows[16 * r] = acc[r];
 
-            // tail of a segment = lookback of the next one
-            if (t >= chain.seg_x - chain.look_u && column < 15)
-            {
-                buf.u[cell(t - chain.seg_x + chain.look_u, column + 1)] = acc[r];
-            }
+            if (t >= chain.seg_x - chain.look_u && lane.column < 15) next[16 * r] = acc[r];
         }
     }
 }
 
 template <int STEPS>
-__device__ __forceinline__ void stage_up (Drb_Fast_Chain const & chain, Buffers const & buf, float const (& a) [STEPS])
+__device__ __forceinline__ void stage_up
+    (
+        Drb_Fast_Chain const & chain, Buffers const & buf, Lane const & lane, int wave, float const (& a) [STEPS]
+    )
 {
-    int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int const blocks = (chain.seg_x + 15) / 16;
 
     // row of x[16 block - N] for block 0, this lane's quarter of the 4-tap step
-    float const * const origin = buf.x + cell(chain.look_x - chain.up_taps + (lane >> 4), lane & 15);
+    float const * const origin = buf.x + 16 * (chain.look_x - chain.up_taps) + lane.operand;
 
     int block = wave;
 
-    for (; block + kWaves < blocks; block += 2 * kWaves)
-    {
-        float b0 [STEPS], b1 [STEPS];
-        float4_t acc0, acc1;
-
-        load_rows<STEPS, 64>(origin + 256 * block, b0);
-        load_rows<STEPS, 64>(origin + 256 * (block + kWaves), b1);
-        multiply_pair<STEPS>(a, b0, b1, acc0, acc1);
-        write_up(chain, buf, block, acc0);
-        write_up(chain, buf, block + kWaves, acc1);
-    }
-
-    if (block < blocks)
+    for (; block < blocks; block += chain.waves)
     {
         float b0 [STEPS];
 
         load_rows<STEPS, 64>(origin + 256 * block, b0);
-        write_up(chain, buf, block, multiply<STEPS>(a, b0));
+        write_up(chain, buf, lane, block, multiply<STEPS>(a, b0));
     }
 }
 
@@ -316,9 +307,10 @@ __device__ __forceinline__ void stage_up (Drb_Fast_Chain const & chain, Buffers 
 template <int STEPS>
 struct Sinc_Type
 {
-    float a [STEPS];   // coefficients at the build phase: row (lane & 15) of the block, taps 4 s + quad - skew
-    float g [STEPS];   // their derivative with respect to the sub-sample position
-    int first_row;     // sinc-input row of the block's first tap
+    float a [STEPS];                 // coefficients now: row (lane & 15) of the block, taps 4 s + quad - skew
+    unsigned g [(STEPS + 1) / 2];    // their derivative with respect to the sub-sample position, as bfloat16
+                                     //   pairs (it only scales a correction of a few 1e-6): even step low
+    int first_row;                   // sinc-input row of the block's first tap
 };
 
 // Reference point of the drift correction: the middle segment's first row.
@@ -398,57 +390,87 @@ __device__ __forceinline__ void build_sinc_type
         }
 
         type.a[s] = live ? value : 0.0f;
-        type.g[s] = live ? slope * rows_per_unit : 0.0f;
+
+        unsigned const rounded = (__float_as_uint(live ? slope * rows_per_unit : 0.0f) + 0x8000u) >> 16;
+
+        if (s & 1) type.g[s / 2] |= rounded << 16; else type.g[s / 2] = rounded;
     }
 
     type.first_row = first_row;
 }
 
+// Rows first .. first + 15 of the sinc output (counted from the segment's
+// start; `in_period` from the period's start), four per lane.
 template <bool DOWN, bool PLAIN>
 __device__ __forceinline__ void write_sinc
     (
         Drb_Fast_Chain const & chain, Drb_Device_Call const & call, Tile const & tile, Buffers const & buf,
-        int channel, long long target_channel_stride, int block, int period, float4_t acc
+        Lane const & lane, DRB_GLOBAL float * target_lane, int channel, long long target_channel_stride,
+        int in_period, int first, float4_t acc
     )
 {
-    int const lane = threadIdx.x & 63, column = lane & 15, quad = lane >> 4;
-    int const in_period = 16 * block + 4 * quad;
-    int const t0 = period * chain.period_out + in_period;   // row of the sinc output = row of d
+    bool const whole = in_period + 16 <= chain.period_out;
 
     if (DOWN)
     {
         // rows alternate between the planes of d; a period may start on either
         int const half = chain.seg_s >> 1;
 
-        #pragma unroll
-        for (int r = 0; r < 4; r++)
+        if (whole && ((first + 15) >> 1) < half - chain.look_d)
         {
-            int const t = t0 + r, g = t >> 1;
+            int const origin = 16 * ((first >> 1) + chain.look_d) + lane.planes;
+            float * const even = buf.d_even + origin, * const odd = buf.d_odd + origin;
 
-            if (in_period + r >= chain.period_out) continue;
-
-            if (t & 1)
+            if (first & 1)
             {
-                buf.d_odd[cell(g + chain.look_d, column)] = acc[r];
-
-                if (g >= half - chain.look_d && column < 15) buf.d_odd[cell(g - half + chain.look_d, column + 1)] = acc[r];
+                odd[0] = acc[0];
+                even[16] = acc[1];
+                odd[16] = acc[2];
+                even[32] = acc[3];
             }
             else
             {
-                buf.d_even[cell_centre(g + chain.look_d, column)] = acc[r];
-
-                if (g >= half - chain.look_d && column < 15) buf.d_even[cell_centre(g - half + chain.look_d, column + 1)] = acc[r];
+                even[0] = acc[0];
+                odd[0] = acc[1];
+                even[16] = acc[2];
+                odd[16] = acc[3];
             }
+
+            return;
+        }
+
+        #pragma unroll
+        for (int r = 0; r < 4; r++)
+        {
+            int const t = first + 4 * lane.quad + r, g = t >> 1;
+
+            if (in_period + 4 * lane.quad + r >= chain.period_out) continue;
+
+            float * const plane = (t & 1) ? buf.d_odd : buf.d_even;
+
+            plane[cell(g + chain.look_d, lane.column)] = acc[r];
+
+            // the tail of a segment is also the lookback of the next one
+            if (g >= half - chain.look_d && lane.column < 15) plane[cell(g - half + chain.look_d, lane.column + 1)] = acc[r];
         }
     }
     else
     {
+        if (lane.column < 1) return;
+
+        if (PLAIN && whole && tile.inside)
+        {
+            *reinterpret_cast<DRB_GLOBAL float4_unaligned *>(target_lane + first) =
+                float4_unaligned{ acc[0], acc[1], acc[2], acc[3] };
+            return;
+        }
+
         #pragma unroll
         for (int r = 0; r < 4; r++)
         {
-            int const frame = tile.base_y + column * chain.seg_y + t0 + r;
+            int const frame = tile.base_y + lane.column * chain.seg_y + first + 4 * lane.quad + r;
 
-            if (in_period + r < chain.period_out && column >= 1 && frame < call.target_frames)
+            if (in_period + 4 * lane.quad + r < chain.period_out && frame < call.target_frames)
             {
                 target_frame<PLAIN>(chain, call, target_channel_stride, channel, frame, acc[r]);
             }
@@ -461,74 +483,51 @@ __device__ __forceinline__ void write_sinc
 // STRIDE floats further.  Behind an up-sampler even rows live in the source
 // plane and odd rows in the up-sampler's output plane, two rows per step.
 template <bool PLANES>
-__device__ __forceinline__ float const * sinc_operand (Drb_Fast_Chain const & chain, Buffers const & buf, int row)
+__device__ __forceinline__ float const * sinc_operand
+    (
+        Drb_Fast_Chain const & chain, float const * lds, Buffers const & buf, Lane const & lane, int row
+    )
 {
-    int const lane = threadIdx.x & 63, column = lane & 15, quad = lane >> 4;
-    int const u = row + quad;
+    if (!PLANES) return buf.u + 16 * (row + chain.look_u) + lane.operand;
 
-    if (!PLANES) return buf.u + cell(u + chain.look_u, column);
-
-    return (u & 1) ? buf.u + cell(((u - 1) >> 1) + chain.look_u, column)
-                   : buf.x + cell(((u - chain.up_taps) >> 1) + chain.look_x, column);
+    return lds + 16 * (row >> 1) + ((row & 1) ? lane.sinc_odd : lane.sinc_even);
 }
 
+// Row-block chains [first, last) of the tile belong to this wave; chain q is
+// period q % periods of block q / periods, and types[i] belongs to the i-th
+// block of the run.
 template <int STEPS, bool PLANES, bool DOWN, bool PLAIN>
 __device__ __forceinline__ void stage_sinc
     (
-        Drb_Fast_Chain const & chain, Drb_Device_Call const & call, Tile const & tile, Buffers const & buf,
+        Drb_Fast_Chain const & chain, Drb_Device_Call const & call, Tile const & tile,
+        float const * lds, Buffers const & buf, Lane const & lane, DRB_GLOBAL float * target_lane,
         int channel, long long target_channel_stride,
-        Sinc_Type<STEPS> const (& types) [kMaxTypes], float drift
+        Sinc_Type<STEPS> const (& types) [kMaxTypes], int first, int last
     )
 {
     constexpr int kStride = PLANES ? 32 : 64;
 
-    int const wave = threadIdx.x >> 6;
-    int const chains = chain.blocks * chain.periods;
-    int const share = (chains + kWaves - 1) / kWaves;
-    int const first = wave * share, last = min(first + share, chains);
     int const first_block = first / chain.periods;
 
-    // One copy of the code for all of the wave's row blocks: the block's
-    // coefficient set is picked out of the (statically indexed) registers.
-    for (int q = first; q < last; )
+    #pragma unroll
+    for (int i = 0; i < kMaxTypes; i++)
     {
-        int const block = q / chain.periods, period = q - block * chain.periods;
-        int const slot = block - first_block;
-        bool const pair = period + 1 < chain.periods && q + 1 < last;
+        int const block = first_block + i;
+        int period = max(first - block * chain.periods, 0);
+        int const period_end = min(last - block * chain.periods, chain.periods);
 
-        float a [STEPS];
-        int first_row = period * chain.period_in;
+        if (period >= period_end) continue;
 
-        // coefficients at this tile's phase; the slot is uniform over the wave
-        #pragma unroll
-        for (int i = 0; i < kMaxTypes; i++)
+        float const (& a) [STEPS] = types[i].a;
+
+        for (; period < period_end; period++)
         {
-            if (__builtin_amdgcn_readfirstlane(slot) == i)
-            {
-                #pragma unroll
-                for (int s = 0; s < STEPS; s++) a[s] = fmaf(drift, types[i].g[s], types[i].a[s]);
+            float b0 [STEPS];
+            int const row = types[i].first_row + period * chain.period_in;
 
-                first_row += types[i].first_row;
-            }
-        }
-
-        float b0 [STEPS], b1 [STEPS];
-        float4_t acc0, acc1;
-
-        load_rows<STEPS, kStride>(sinc_operand<PLANES>(chain, buf, first_row), b0);
-
-        if (pair)
-        {
-            load_rows<STEPS, kStride>(sinc_operand<PLANES>(chain, buf, first_row + chain.period_in), b1);
-            multiply_pair<STEPS>(a, b0, b1, acc0, acc1);
-            write_sinc<DOWN, PLAIN>(chain, call, tile, buf, channel, target_channel_stride, block, period, acc0);
-            write_sinc<DOWN, PLAIN>(chain, call, tile, buf, channel, target_channel_stride, block, period + 1, acc1);
-            q += 2;
-        }
-        else
-        {
-            write_sinc<DOWN, PLAIN>(chain, call, tile, buf, channel, target_channel_stride, block, period, multiply<STEPS>(a, b0));
-            q += 1;
+            load_rows<STEPS, kStride>(sinc_operand<PLANES>(chain, lds, buf, lane, row), b0);
+            write_sinc<DOWN, PLAIN>(chain, call, tile, buf, lane, target_lane, channel, target_channel_stride,
+                                    16 * block, period * chain.period_out + 16 * block, multiply<STEPS>(a, b0));
         }
     }
 }
@@ -539,36 +538,34 @@ template <bool PLAIN>
 __device__ __forceinline__ void write_down
     (
         Drb_Fast_Chain const & chain, Drb_Device_Call const & call, Tile const & tile, Buffers const & buf,
-        int channel, long long target_channel_stride, int block, float4_t acc
+        Lane const & lane, DRB_GLOBAL float * target_lane, int channel, long long target_channel_stride,
+        int block, float4_t acc
     )
 {
-    int const lane = threadIdx.x & 63, column = lane & 15, quad = lane >> 4;
-    int const t0 = 16 * block + 4 * quad;
-    int const frame0 = tile.base_y + column * chain.seg_y + t0;
+    float const * const centre = buf.d_even + 16 * (16 * block - chain.down_taps / 2 + chain.look_d) + lane.result;
     float value [4];
 
     #pragma unroll
-    for (int r = 0; r < 4; r++)
-    {
-        float const centre = buf.d_even[cell_centre(t0 + r - chain.down_taps / 2 + chain.look_d, column)];
-        value[r] = fmaf(0.5f, centre, acc[r]);
-    }
+    for (int r = 0; r < 4; r++) value[r] = fmaf(0.5f, centre[16 * r], acc[r]);
 
-    if (column < 1) return;
+    if (lane.column < 1) return;
 
-    if (PLAIN && t0 + 3 < chain.seg_y && frame0 + 3 < call.target_frames)
+    if (PLAIN && tile.inside && 16 * block + 16 <= chain.seg_y)
     {
-        DRB_GLOBAL float * const out = global_pointer<float>(call.target) + channel * target_channel_stride + frame0;
-        *reinterpret_cast<DRB_GLOBAL float4_unaligned *>(out) = float4_unaligned{ value[0], value[1], value[2], value[3] };
+        *reinterpret_cast<DRB_GLOBAL float4_unaligned *>(target_lane + 16 * block) =
+            float4_unaligned{ value[0], value[1], value[2], value[3] };
         return;
     }
 
     #pragma unroll
     for (int r = 0; r < 4; r++)
     {
-        if (t0 + r < chain.seg_y && frame0 + r < call.target_frames)
+        int const t = 16 * block + 4 * lane.quad + r;
+        int const frame = tile.base_y + lane.column * chain.seg_y + t;
+
+        if (t < chain.seg_y && frame < call.target_frames)
         {
-            target_frame<PLAIN>(chain, call, target_channel_stride, channel, frame0 + r, value[r]);
+            target_frame<PLAIN>(chain, call, target_channel_stride, channel, frame, value[r]);
         }
     }
 }
@@ -577,125 +574,161 @@ template <int STEPS, bool PLAIN>
 __device__ __forceinline__ void stage_down
     (
         Drb_Fast_Chain const & chain, Drb_Device_Call const & call, Tile const & tile, Buffers const & buf,
-        int channel, long long target_channel_stride, float const (& a) [STEPS]
+        Lane const & lane, DRB_GLOBAL float * target_lane, int channel, long long target_channel_stride,
+        int wave, float const (& a) [STEPS]
     )
 {
-    int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int const blocks = (chain.seg_y + 15) / 16;
-    float const * const origin = buf.d_odd + cell(chain.look_d - chain.down_taps + (lane >> 4), lane & 15);
+    float const * const origin = buf.d_odd + 16 * (chain.look_d - chain.down_taps) + lane.operand;
 
-    int block = wave;
+    // where the blocks do not divide evenly, the waves that carried one more in
+    // the up-sampler carry one less here
+    int block = wave + (chain.waves >> 1);
 
-    for (; block + kWaves < blocks; block += 2 * kWaves)
-    {
-        float b0 [STEPS], b1 [STEPS];
-        float4_t acc0, acc1;
+    if (block >= chain.waves) block -= chain.waves;
 
-        load_rows<STEPS, 64>(origin + 256 * block, b0);
-        load_rows<STEPS, 64>(origin + 256 * (block + kWaves), b1);
-        multiply_pair<STEPS>(a, b0, b1, acc0, acc1);
-        write_down<PLAIN>(chain, call, tile, buf, channel, target_channel_stride, block, acc0);
-        write_down<PLAIN>(chain, call, tile, buf, channel, target_channel_stride, block + kWaves, acc1);
-    }
-
-    if (block < blocks)
+    for (; block < blocks; block += chain.waves)
     {
         float b0 [STEPS];
 
         load_rows<STEPS, 64>(origin + 256 * block, b0);
-        write_down<PLAIN>(chain, call, tile, buf, channel, target_channel_stride, block, multiply<STEPS>(a, b0));
+        write_down<PLAIN>(chain, call, tile, buf, lane, target_lane, channel, target_channel_stride, block,
+                          multiply<STEPS>(a, b0));
     }
 }
 
 // ---- source tile: global -> registers -> LDS -------------------------------------------
 
-constexpr int kFetchMax = 4;   // float4 per thread: up to 4 * 64 = 256 rows of 16 segments
-
+// FETCH float4 per thread: up to (threads / 4) FETCH rows of 16 segments
+template <int FETCH>
 struct Fetch
 {
-    float4_t v [kFetchMax];
+    float4_t v [FETCH];
 };
 
-// Thread t holds rows 4 (t >> 4) + 64 i + {0..3} of segment t & 15.
-template <bool PLAIN>
+// Thread t fetches rows 4 (t >> 4) + (threads / 4) i + {0..3} of segment t & 15 as one
+// dwordx4 from the step's chunk or from the stream's history, whichever holds
+// all four frames.  The loads are unconditional (a group that straddles a seam
+// or an end reads the last history frames instead and is mended when the tile
+// is stored), so that nothing waits for them before then.
+template <int FETCH>
 __device__ __forceinline__ void fetch_tile
     (
         Drb_Fast_Chain const & chain, Drb_Device_Call const & call, int base_x,
-        float const * history, long long source_channel_stride, int channel, Fetch & fetch
+        float const * history, long long source_channel_stride, int channel, Fetch<FETCH> & fetch
+    )
+{
+    int const first = base_x + (threadIdx.x & 15) * chain.seg_x + 4 * (threadIdx.x >> 4) - chain.look_x;
+    int const pass = 16 * chain.waves;   // rows the workgroup fetches per dwordx4 each
+    DRB_GLOBAL float const * const source = global_pointer<float const>(call.source) + channel * source_channel_stride;
+    DRB_GLOBAL float const * const past =
+        global_pointer<float const>(reinterpret_cast<unsigned long long>(history)) + channel * chain.history + chain.history;
+
+    #pragma unroll
+    for (int i = 0; i < FETCH; i++)
+    {
+        // (also for groups past the tile's last row: a load that depends on
+        // nothing is cheaper than one the next tile's loads have to wait for)
+        int const frame = first + pass * i;
+        bool const in_chunk = frame >= 0 && frame + 4 <= call.source_frames;
+        bool const in_past = frame + 4 <= 0 && frame >= -chain.history;
+        DRB_GLOBAL float const * const from = in_chunk ? source + frame : past + (in_past ? frame : -4);
+
+        fetch.v[i] = *reinterpret_cast<DRB_GLOBAL float4_unaligned const *>(from);
+    }
+}
+
+template <int FETCH>
+__device__ __forceinline__ void store_tile
+    (
+        Drb_Fast_Chain const & chain, Drb_Device_Call const & call, Buffers const & buf, int base_x,
+        float const * history, long long source_channel_stride, int channel, Fetch<FETCH> & fetch
     )
 {
     int const segment = threadIdx.x & 15, group = threadIdx.x >> 4;
     int const rows = chain.seg_x + chain.look_x;
-    int const first_frame = base_x + segment * chain.seg_x + 4 * group - chain.look_x;
+    int const first = base_x + segment * chain.seg_x + 4 * group - chain.look_x;
+    int const pass = 16 * chain.waves;
+    float * const mine = buf.x + cell(4 * group, segment);
 
-    // Interior tiles of planar float streams (the common case, decided for the
-    // whole workgroup): every row is a plain dwordx4 load and nothing waits.
-    bool const interior = PLAIN
-        && base_x - chain.look_x >= 0
-        && base_x + 15 * chain.seg_x + ((rows + 3) & ~3) + 64 <= call.source_frames;
-
-    if (interior)
+    #pragma unroll
+    for (int i = 0; i < FETCH; i++)
     {
-        DRB_GLOBAL float const * const planar =
-            global_pointer<float const>(call.source) + channel * source_channel_stride + first_frame;
+        // every fetched group counts as used here, whichever rows below take
+        // it: no load may look pending once the tile is stored
+        asm volatile ("" : "+v"(fetch.v[i]));
 
-        #pragma unroll
-        for (int i = 0; i < kFetchMax; i++)
+        if (pass * i >= rows) continue;
+
+        // groups of four frames across a seam or an end: one by one
         {
-            if (64 * i < rows)
+            int const frame = first + pass * i;
+            bool const in_chunk = frame >= 0 && frame + 4 <= call.source_frames;
+            bool const in_past = frame + 4 <= 0 && frame >= -chain.history;
+
+            if (!in_chunk && !in_past)
             {
-                fetch.v[i] = *reinterpret_cast<DRB_GLOBAL float4_unaligned const *>(planar + 64 * i);
+                #pragma unroll
+                for (int e = 0; e < 4; e++)
+                {
+                    fetch.v[i][e] = source_frame<true>(chain, call, history, source_channel_stride, channel, frame + e);
+                }
+
+                asm volatile ("" : "+v"(fetch.v[i]));   // as above
             }
         }
 
-        return;
-    }
-
-    // stream edges, history, other sample types and layouts: one by one
-    #pragma unroll
-    for (int i = 0; i < kFetchMax; i++)
-    {
-        if (64 * i < rows)
+        if (pass * i + pass <= rows)
+        {
+            #pragma unroll
+            for (int e = 0; e < 4; e++) mine[16 * (pass * i + e)] = fetch.v[i][e];
+        }
+        else
         {
             #pragma unroll
             for (int e = 0; e < 4; e++)
             {
-                fetch.v[i][e] = source_frame<PLAIN>(chain, call, history, source_channel_stride, channel,
-                                             first_frame + 64 * i + e);
+                if (4 * group + pass * i + e < rows) mine[16 * (pass * i + e)] = fetch.v[i][e];
             }
         }
     }
 }
 
-__device__ __forceinline__ void store_tile (Drb_Fast_Chain const & chain, Buffers const & buf, Fetch const & fetch)
+// Stream edges, history, other sample types and layouts: one sample at a time,
+// straight into LDS.
+template <bool PLAIN>
+__device__ __forceinline__ void load_tile_slowly
+    (
+        Drb_Fast_Chain const & chain, Drb_Device_Call const & call, Buffers const & buf, int base_x,
+        float const * history, long long source_channel_stride, int channel
+    )
 {
-    int const segment = threadIdx.x & 15, group = threadIdx.x >> 4;
     int const rows = chain.seg_x + chain.look_x;
 
-    #pragma unroll
-    for (int i = 0; i < kFetchMax; i++)
+    #pragma unroll 1
+    for (int i = threadIdx.x; i < 16 * rows; i += blockDim.x)
     {
-        #pragma unroll
-        for (int e = 0; e < 4; e++)
-        {
-            int const row = 4 * group + 64 * i + e;
+        int const segment = i & 15, row = i >> 4;
 
-            if (row < rows) buf.x[cell(row, segment)] = fetch.v[i][e];
-        }
+        buf.x[i] = source_frame<PLAIN>(chain, call, history, source_channel_stride, channel,
+                                       base_x + segment * chain.seg_x + row - chain.look_x);
     }
 }
 
 // Diagnostic build only (-DDRB_FAST_STAMPS): where a wave's cycles go, summed
-// per phase into fault_flag[1 + 16 wave_class + phase] (the flag word itself is
-// word 0).  Never compiled into the library that ships.
+// per phase into fault_flag[1 + 16 wave + phase] (the flag word itself is
+// word 0), and chain.ablate switches stages off.  Never compiled into the
+// library that ships.
 #ifdef DRB_FAST_STAMPS
 #  define STAMP(phase) do { long long const now_ = __builtin_readcyclecounter(); spent[phase] += now_ - mark; mark = now_; } while (0)
+#  define ABLATED(bit) (chain.ablate & (bit))
 #else
 #  define STAMP(phase) do { } while (0)
+#  define ABLATED(bit) false
 #endif
 
-template <int UP_STEPS, int SINC_STEPS, int DOWN_STEPS, bool PLAIN>
-__global__ __launch_bounds__(kThreads, 2) void drb_fast_kernel
+template <int UP_STEPS, int SINC_STEPS, int DOWN_STEPS, int FETCH, bool PLAIN>
+__global__ __launch_bounds__(kMaxThreads, 3) void drb_fast_kernel
     (
         Drb_Fast_Chain const chain,
         Drb_Device_Call const * __restrict__ calls, int stream_count, int tile_stride,
@@ -713,77 +746,95 @@ __global__ __launch_bounds__(kThreads, 2) void drb_fast_kernel
 
     if (first_tile * chain.tile_frames >= call.target_frames) return;
 
-    int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6, column = lane & 15, quad = lane >> 4;
+    // the same for all lanes of a wave: kept in a scalar register so that what
+    // depends on it branches instead of masking lanes
+    int const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    Lane lane;
+
+    lane.column = threadIdx.x & 15;
+    lane.quad = (threadIdx.x & 63) >> 4;
+    lane.operand = cell(lane.quad, lane.column);
+    lane.result = cell(4 * lane.quad, lane.column);
+    lane.planes = cell(2 * lane.quad, lane.column);
+
+    // Behind an up-sampler, sinc-input row F + quad (F even) is source-plane
+    // row (F + quad - N) / 2 for even quads and odd-plane row (F + quad - 1) / 2
+    // for odd ones; one row further on, the planes swap.
+    {
+        int const source = chain.off_x + 16 * (chain.look_x - chain.up_taps / 2) + lane.column;
+        int const odd = chain.off_u + 16 * chain.look_u + lane.column;
+
+        lane.sinc_even = (lane.quad & 1) ? odd + 16 * (lane.quad >> 1) : source + 16 * (lane.quad >> 1);
+        lane.sinc_odd = (lane.quad & 1) ? source + 16 * ((lane.quad + 1) >> 1) : odd + 16 * (lane.quad >> 1);
+    }
 
     Buffers const buf = { lds + chain.off_x, lds + chain.off_u, lds + chain.off_d_odd,
                           lds + chain.off_d_even, lds + chain.off_bank };
     float const * const stream_history = history + static_cast<long long>(stream) * chain.channels * chain.history;
 
     // ---- once per workgroup -----------------------------------------------------
-    // coefficient bank of the fractional stage -> LDS as [tap][row]
-    {
-        int const taps = chain.sinc_taps, rows = chain.sinc_cubic ? 32 : 64;
-        float const * const source = table_at(chain.sinc_table);
+    // Half-band taps with 16 zeros in front and behind.  Row m of a 16-row block
+    // multiplies input k of the block's window by
+    //   up:   2 h[k - m - 1]   (window starts at row 16 block - N)
+    //   down:   h[k - m]
+    // so a lane (m = column, k = 4 step + quad) reads its A operands four floats
+    // apart from one place in the table.
+    float * const taps_up = lds + chain.off_taps;
+    float * const taps_down = taps_up + chain.up_taps + 32;
 
-        for (int i = threadIdx.x; i < rows * taps; i += kThreads)
-        {
-            int const row = i / taps, tap = i - row * taps;
-            buf.bank[tap * kBankRowStride + row] = source[i];
-        }
+    for (int i = threadIdx.x; i < chain.up_taps + 32; i += blockDim.x)
+    {
+        int const j = i - 16;
+        taps_up[i] = UP_STEPS && j >= 0 && j < chain.up_taps ? 2.0f * table_at(chain.up_table)[j] : 0.0f;
     }
 
-    // half-band coefficients as banded A fragments, parked in LDS as [step][lane]
-    // (the same for every wave) and fetched by the stage that uses them:
-    //   up:   A[m][k] = 2 h[k - m - 1]   (block window starts at row 16 i - N)
-    //   down: A[m][k] =   h[k - m]
-    float * const park_up = buf.bank + chain.sinc_taps * kBankRowStride + 8;
-    float * const park_down = park_up + 64 * UP_STEPS;
-
-    if (wave == 0)
+    for (int i = threadIdx.x; i < chain.down_taps + 32; i += blockDim.x)
     {
-        #pragma unroll
-        for (int s = 0; s < UP_STEPS; s++)
-        {
-            int const j = 4 * s + quad - column - 1;
-            park_up[64 * s + lane] = j >= 0 && j < chain.up_taps ? 2.0f * table_at(chain.up_table)[j] : 0.0f;
-        }
-
-        #pragma unroll
-        for (int s = 0; s < DOWN_STEPS; s++)
-        {
-            int const j = 4 * s + quad - column;
-            park_down[64 * s + lane] = j >= 0 && j < chain.down_taps ? table_at(chain.down_table)[j] : 0.0f;
-        }
+        int const j = i - 15;
+        taps_down[i] = DOWN_STEPS && j >= 0 && j < chain.down_taps ? table_at(chain.down_table)[j] : 0.0f;
     }
+
+    float const * const a_up_lane = taps_up + 15 + lane.quad - lane.column;
+    float const * const a_down_lane = taps_down + 15 + lane.quad - lane.column;
 
     int const delay_behind = chain.delay_place == 1 ? call.delay : 0;
     int const delay_front = chain.delay_place == 2 ? call.delay : 0;
     int const tile_advance_s = (DOWN_STEPS ? 2 : 1) * chain.tile_frames;   // sinc outputs per tile
 
+    // this wave's run of the fractional stage's row-block chains
+    int const chains = chain.blocks * chain.periods;
+    int const share = (chains + chain.waves - 1) / chain.waves;
+    int const first_chain = wave * share, last_chain = min(first_chain + share, chains);
+
 #ifdef DRB_FAST_STAMPS
-    long long spent [10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    long long spent [11] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     long long mark = __builtin_readcyclecounter();
 #endif
 
     Sinc_Type<SINC_STEPS> types [kMaxTypes];
     Sinc_Anchor anchor = { 0, 0, 0, 0 };
+    float applied_drift = 0.0f;
     int since_build = kRebuild;
-    Fetch fetch;
-    bool fetched = false;
+    Fetch<FETCH> fetch;
 
-    // ---- tiles of this stream and channel ------------------------------------------
-    for (int tile_index = first_tile; tile_index * chain.tile_frames < call.target_frames; tile_index += tile_stride)
+    // Places tile `index`: from the exact phase every kRebuild tiles, by whole
+    // periods in between.
+    auto place = [&] (int index) -> Tile
     {
         Tile tile;
 
+        tile.index = index;
+        tile.fetched = false;
+
         // segment 1 starts at the tile's first target frame
-        tile.base_y = tile_index * chain.tile_frames - chain.seg_y;
+        tile.base_y = index * chain.tile_frames - chain.seg_y;
         tile.base_s = (DOWN_STEPS ? 2 * tile.base_y : tile.base_y) - delay_behind;
+        tile.inside = tile.base_y + 16 * chain.seg_y <= call.target_frames;
+        tile.rebuild = since_build >= kRebuild;
+        tile.drift = 0.0f;
 
-        bool const rebuild = since_build >= kRebuild;
-        float drift = 0.0f;
-
-        if (rebuild)
+        if (tile.rebuild)
         {
             // window ends of the middle segment (8) define the phases of all segments
             int consumed;
@@ -819,19 +870,36 @@ __global__ __launch_bounds__(kThreads, 2) void drb_fast_kernel
             long long const advance = static_cast<long long>(tile.base_s - anchor.base_s) * chain.target_delta
                                     - static_cast<long long>(tile.base_u - anchor.base_u) * chain.source_delta;
 
-            drift = static_cast<float>(static_cast<double>(advance) * chain.scale);
+            tile.drift = static_cast<float>(static_cast<double>(advance) * chain.scale);
         }
 
         since_build += 1;
 
-        if (!fetched && !(chain.ablate & 1))
-        {
-            fetch_tile<PLAIN>(chain, call, tile.base_x, stream_history, source_channel_stride, channel, fetch);
-        }
+        return tile;
+    };
+
+    // ---- tiles of this stream and channel ------------------------------------------
+    Tile tile = place(first_tile);
+
+    if (PLAIN && !ABLATED(1))
+    {
+        fetch_tile(chain, call, tile.base_x, stream_history, source_channel_stride, channel, fetch);
+        store_tile(chain, call, buf, tile.base_x, stream_history, source_channel_stride, channel, fetch);
+        tile.fetched = true;
+    }
+
+    for (;;)
+    {
+        DRB_GLOBAL float * const target_lane = global_pointer<float>(call.target) + channel * target_channel_stride
+            + tile.base_y + lane.column * chain.seg_y + 4 * lane.quad;
 
         STAMP(0);
 
-        if (!(chain.ablate & 1)) store_tile(chain, buf, fetch);
+        // a tile fetched ahead is in LDS already (see below)
+        if (!tile.fetched && !ABLATED(1))
+        {
+            load_tile_slowly<PLAIN>(chain, call, buf, tile.base_x, stream_history, source_channel_stride, channel);
+        }
 
         STAMP(1);
 
@@ -839,26 +907,25 @@ __global__ __launch_bounds__(kThreads, 2) void drb_fast_kernel
 
         STAMP(2);
 
-        // the next tile's source travels while this one is filtered
+        if (tile.rebuild && !ABLATED(4))
         {
-            int const next_index = tile_index + tile_stride;
-
-            fetched = next_index * chain.tile_frames < call.target_frames && since_build < kRebuild;
-
-            if (fetched && !(chain.ablate & 1))
+            // The coefficient bank of the fractional stage comes to LDS as
+            // [tap][row] for the occasion: it may lie where d's planes are,
+            // which nobody touches between the barrier above and the next one.
             {
-                fetch_tile<PLAIN>(chain, call, tile.base_x + tile_stride * 15 * chain.seg_x, stream_history,
-                           source_channel_stride, channel, fetch);
+                int const taps = chain.sinc_taps, rows = chain.sinc_cubic ? 32 : 64;
+                float const * const source = table_at(chain.sinc_table);
+
+                for (int i = threadIdx.x; i < rows * taps; i += blockDim.x)
+                {
+                    int const row = i / taps, tap = i - row * taps;
+                    buf.bank[tap * kBankRowStride + row] = source[i];
+                }
+
+                __syncthreads();
             }
-        }
 
-        STAMP(3);
-
-        if (rebuild && !(chain.ablate & 4))
-        {
-            int const chains = chain.blocks * chain.periods;
-            int const share = (chains + kWaves - 1) / kWaves;
-            int const first_block = wave * share / chain.periods;
+            int const first_block = first_chain / chain.periods;
 
             #pragma unroll
             for (int i = 0; i < kMaxTypes; i++)
@@ -868,18 +935,28 @@ __global__ __launch_bounds__(kThreads, 2) void drb_fast_kernel
                     build_sinc_type<SINC_STEPS>(chain, call, anchor, buf.bank, first_block + i, types[i], fault_flag);
                 }
             }
+
+            __syncthreads();   // the bank's place may be written again
+
+            applied_drift = 0.0f;
         }
 
         STAMP(4);
 
+        int const next_index = tile.index + tile_stride;
+        bool const more = next_index * chain.tile_frames < call.target_frames;
+        Tile next = tile;
+
+        STAMP(3);
+
         if (UP_STEPS > 0)
         {
-            if (!(chain.ablate & 2))
+            if (!ABLATED(2))
             {
                 float a_up [UP_STEPS ? UP_STEPS : 1];
 
-                load_rows<UP_STEPS ? UP_STEPS : 1, 64>(park_up + lane, a_up);
-                stage_up<UP_STEPS ? UP_STEPS : 1>(chain, buf, a_up);
+                load_rows<UP_STEPS ? UP_STEPS : 1, 4>(a_up_lane, a_up);
+                stage_up<UP_STEPS ? UP_STEPS : 1>(chain, buf, lane, wave, a_up);
             }
 
             STAMP(5);
@@ -889,9 +966,46 @@ __global__ __launch_bounds__(kThreads, 2) void drb_fast_kernel
             STAMP(6);
         }
 
-        if (!(chain.ablate & 4))
+        // The next tile's source travels while this one is filtered.  Asked for
+        // here rather than earlier: loads queue behind the stores of the previous
+        // tile's down-sampler, which by now have long gone.  Fetching and storing
+        // happen whether or not a tile follows (the last one fetches its own rows
+        // again): every load then meets its wait within the iteration, and none
+        // looks pending when the loop comes round to load into the same registers.
+        if (more) next = place(next_index);
+
+        if (PLAIN && !ABLATED(1))
         {
-            stage_sinc<SINC_STEPS, (UP_STEPS > 0), (DOWN_STEPS > 0), PLAIN>(chain, call, tile, buf, channel, target_channel_stride, types, drift);
+            fetch_tile(chain, call, next.base_x, stream_history, source_channel_stride, channel, fetch);
+            next.fetched = true;
+        }
+
+        STAMP(10);
+
+        // coefficients follow the phase from the previous tile's to this tile's
+        {
+            float const step = tile.drift - applied_drift;
+
+            #pragma unroll
+            for (int i = 0; i < kMaxTypes; i++)
+            {
+                #pragma unroll
+                for (int s = 0; s < SINC_STEPS; s++)
+                {
+                    unsigned const pair = types[i].g[s / 2];
+                    float const slope = __uint_as_float((s & 1) ? pair & 0xffff0000u : pair << 16);
+
+                    types[i].a[s] = fmaf(step, slope, types[i].a[s]);
+                }
+            }
+
+            applied_drift = tile.drift;
+        }
+
+        if (!ABLATED(4))
+        {
+            stage_sinc<SINC_STEPS, (UP_STEPS > 0), (DOWN_STEPS > 0), PLAIN>
+                (chain, call, tile, lds, buf, lane, target_lane, channel, target_channel_stride, types, first_chain, last_chain);
         }
 
         STAMP(7);
@@ -900,21 +1014,34 @@ __global__ __launch_bounds__(kThreads, 2) void drb_fast_kernel
 
         STAMP(8);
 
-        if (DOWN_STEPS > 0 && !(chain.ablate & 8))
+        // The next tile's rows have long arrived; they go to LDS here rather
+        // than at the top of the loop, where waiting for them would also wait
+        // for the stores of the down-sampler below.
+        if (PLAIN && !ABLATED(1))
+        {
+            store_tile(chain, call, buf, next.base_x, stream_history, source_channel_stride, channel, fetch);
+        }
+
+        if (DOWN_STEPS > 0 && !ABLATED(8))
         {
             float a_down [DOWN_STEPS ? DOWN_STEPS : 1];
 
-            load_rows<DOWN_STEPS ? DOWN_STEPS : 1, 64>(park_down + lane, a_down);
-            stage_down<DOWN_STEPS ? DOWN_STEPS : 1, PLAIN>(chain, call, tile, buf, channel, target_channel_stride, a_down);
+            load_rows<DOWN_STEPS ? DOWN_STEPS : 1, 4>(a_down_lane, a_down);
+            stage_down<DOWN_STEPS ? DOWN_STEPS : 1, PLAIN>
+                (chain, call, tile, buf, lane, target_lane, channel, target_channel_stride, wave, a_down);
         }
 
         STAMP(9);
+
+        if (!more) break;
+
+        tile = next;
     }
 
 #ifdef DRB_FAST_STAMPS
-    if (lane == 0)
+    if ((threadIdx.x & 63) == 0)
     {
-        for (int phase = 0; phase < 10; phase++)
+        for (int phase = 0; phase < 11; phase++)
         {
             atomicAdd(reinterpret_cast<unsigned long long *>(fault_flag) + 1 + 16 * wave + phase,
                       static_cast<unsigned long long>(spent[phase]));
@@ -928,29 +1055,35 @@ typedef void Fast_Kernel
         Drb_Fast_Chain, Drb_Device_Call const *, int, int, float const *, long long, long long, int *
     );
 
-// The kernel images that exist: (up steps, sinc steps, down steps), steps =
-// (taps + 16) / 4 for a half-band, chain.ksteps for the fractional stage.
+// The kernel images that exist: (up steps, sinc steps, down steps, groups of 64
+// source rows a tile has at most), steps = (taps + 16) / 4 for a half-band,
+// chain.ksteps for the fractional stage.
 Fast_Kernel * pick_kernel (Drb_Fast_Chain const * chain)
 {
     int const up = chain->has_up ? (chain->up_taps + 16) / 4 : 0;
     int const down = chain->has_down ? (chain->down_taps + 16) / 4 : 0;
     int const key = up * 10000 + chain->ksteps * 100 + down;
+    int const rows = chain->seg_x + chain->look_x;
+    int const pass = 16 * chain->waves;
+
+    if (chain->waves * 64 > kMaxThreads || chain->waves < 1) return nullptr;
 
     bool const plain = chain->sample_type == kSampleF32 && chain->layout == kPlanar;
 
-#define DRB_FAST_CASE(KEY, UP, SINC, DOWN) \
-      case KEY: return plain ? drb_fast_kernel<UP, SINC, DOWN, true> : drb_fast_kernel<UP, SINC, DOWN, false>;
+#define DRB_FAST_CASE(KEY, UP, SINC, DOWN, FETCH) \
+      case KEY: if (rows > pass * FETCH) return nullptr; \
+                return plain ? drb_fast_kernel<UP, SINC, DOWN, FETCH, true> : drb_fast_kernel<UP, SINC, DOWN, FETCH, false>;
 
     switch (key)
     {
-      DRB_FAST_CASE(141214, 14, 12, 14)   // good, rate going up
-      DRB_FAST_CASE(141314, 14, 13, 14)   // good, rate going down
-      DRB_FAST_CASE(120812, 12, 8, 12)    // fine
-      DRB_FAST_CASE(120912, 12, 9, 12)
-      DRB_FAST_CASE(161216, 16, 12, 16)   // best
-      DRB_FAST_CASE(161316, 16, 13, 16)
-      DRB_FAST_CASE(800, 0, 8, 0)         // poor
-      DRB_FAST_CASE(900, 0, 9, 0)
+      DRB_FAST_CASE(141214, 14, 12, 14, 3)   // good, rate going up
+      DRB_FAST_CASE(141314, 14, 13, 14, 4)   // good, rate going down
+      DRB_FAST_CASE(120812, 12, 8, 12, 3)    // fine
+      DRB_FAST_CASE(120912, 12, 9, 12, 3)
+      DRB_FAST_CASE(161216, 16, 12, 16, 4)   // best
+      DRB_FAST_CASE(161316, 16, 13, 16, 4)
+      DRB_FAST_CASE(800, 0, 8, 0, 4)         // poor
+      DRB_FAST_CASE(900, 0, 9, 0, 4)
     }
 
 #undef DRB_FAST_CASE
@@ -1007,7 +1140,7 @@ extern "C" int drb_hip_launch_fast
 
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
 
-    kernel<<<dim3(static_cast<unsigned>(blocks)), dim3(kThreads), dynamic, static_cast<hipStream_t>(stream)>>>
+    kernel<<<dim3(static_cast<unsigned>(blocks)), dim3(static_cast<unsigned>(64 * chain->waves)), dynamic, static_cast<hipStream_t>(stream)>>>
     (
         *chain, calls, stream_count, static_cast<int>(tile_stride), history,
         source_channel_stride, target_channel_stride, fault_flag

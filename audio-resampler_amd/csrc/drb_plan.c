@@ -738,21 +738,79 @@ int drb_plan_fast_geometry (Drb_Plan const * plan, int lds_budget_bytes, Drb_Fas
         offset += (chain->seg_s / 2 + chain->look_d) * 16;
     }
 
-    chain->off_bank = offset;
-    offset += taps * 65 + 8; /* the bank as [tap][row], 65 floats between taps */
-    offset += 64 * ((chain->up_taps + 16) / 4 + (chain->down_taps + 16) / 4); /* half-band coefficient fragments */
+    /* The bank, [tap][row] with 65 floats between taps, is only read while
+     * coefficients are rebuilt, when the planes of d are idle: it shares them. */
+    {
+        int const bank = taps * 65 + 8;
+
+        if (down >= 0 && bank <= offset - chain->off_d_odd)
+        {
+            chain->off_bank = chain->off_d_odd;
+        }
+        else
+        {
+            chain->off_bank = offset;
+            offset += bank;
+        }
+    }
+
+    /* half-band taps between 16 zeros on either side (what a banded 16-row
+     * block multiplies by depends on tap index minus row only) */
+    chain->off_taps = offset;
+    offset += (chain->up_taps + 32) + (chain->down_taps + 32);
     chain->lds_floats = offset + 32;
 
     if (chain->lds_floats * 4 > lds_budget_bytes) return 0;
 
-    /* row blocks of the sinc stage are dealt to the four waves in runs */
+    /* Waves per workgroup.  Every stage deals whole 16-row blocks to the waves
+     * and ends in a barrier, so a stage takes as long as the wave with most
+     * blocks.  Five waves would deal the usual 10 + 20 + 10 blocks out evenly,
+     * but measured slower on MI355X: a CU has four SIMDs, the fifth wave doubles
+     * up on one of them and fewer workgroups fit.  Row blocks of the sinc stage
+     * go to the waves in runs, and a wave keeps coefficients for at most three
+     * block types. */
     {
         int const chains = chain->blocks * chain->periods;
-        int const share = (chains + 3) / 4;
+        int const up_blocks = up >= 0 ? (chain->seg_x + 15) / 16 : 0;
+        int const down_blocks = down >= 0 ? (chain->seg_y + 15) / 16 : 0;
+        int const up_steps = up >= 0 ? (chain->up_taps + 16) / 4 : 0;
+        int const down_steps = down >= 0 ? (chain->down_taps + 16) / 4 : 0;
+        long best = 0;
 
-        chain->types_per_wave = (share + chain->periods - 2) / chain->periods + 1;
+        chain->waves = 0;
 
-        if (chain->types_per_wave > 3) return 0;
+        for (int waves = 4; waves <= 4; waves++)
+        {
+            int const share = (chains + waves - 1) / waves;
+            int types = 0;
+
+            for (int w = 0; w < waves; w++)
+            {
+                int const first = w * share, last = first + share < chains ? first + share : chains;
+
+                if (first < last)
+                {
+                    int const span = (last - 1) / chain->periods - first / chain->periods + 1;
+                    if (span > types) types = span;
+                }
+            }
+
+            if (types > 3) continue;
+            if ((chain->seg_x + chain->look_x + 16 * waves - 1) / (16 * waves) > 4) continue;
+
+            long const cost = (long)((up_blocks + waves - 1) / waves) * up_steps
+                            + (long)share * chain->ksteps
+                            + (long)((down_blocks + waves - 1) / waves) * down_steps;
+
+            if (chain->waves == 0 || cost < best)
+            {
+                chain->waves = waves;
+                chain->types_per_wave = types;
+                best = cost;
+            }
+        }
+
+        if (chain->waves == 0) return 0;
     }
 
     chain->tile_frames = 15 * chain->seg_y;

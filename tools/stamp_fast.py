@@ -15,7 +15,7 @@ import torch
 
 import drbamd
 
-PHASES = ["place", "store_x", "wait_b0", "prefetch", "build", "up", "wait_b1", "sinc", "wait_b2", "down"]
+PHASES = ["top", "load_x", "wait_b0", "misc", "build", "up", "wait_b1", "sinc", "wait_b2", "down", "prefetch"]
 
 
 def main():
@@ -27,20 +27,20 @@ def main():
     src = torch.rand((streams, ch, frames), device="cuda") * 2 - 1
     dst = torch.zeros((streams, ch, cap), device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
-    counters = (ctypes.c_ulonglong * 64)()
+    counters = (ctypes.c_ulonglong * 96)()
     drbamd.lib.drb_amd_debug_counters.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
     for step in range(3):
         batch.process_dense(src.data_ptr(), ch * frames, frames, dst.data_ptr(), ch * cap, cap,
                             frames, cap, stream=stream)
         batch.synchronize(stream)
-        drbamd.check(drbamd.lib.drb_amd_debug_counters(batch.handle, counters, 64))
+        drbamd.check(drbamd.lib.drb_amd_debug_counters(batch.handle, counters, 96))
     total_all = 0
     for wave in range(4):
-        row = [counters[16 * wave + p] for p in range(10)]
+        row = [counters[16 * wave + p] for p in range(len(PHASES))]
         total = sum(row)
         total_all += total
         print("wave %d  total %.1f Mcycles  " % (wave, total / 1e6)
-              + "  ".join("%s %.1f%%" % (PHASES[p], 100.0 * row[p] / total) for p in range(10)))
+              + "  ".join("%s %.1f%%" % (PHASES[p], 100.0 * row[p] / total) for p in range(len(PHASES))))
     print("cycles per tile iteration per wave: %.0f" % (total_all / 4 / (streams * ch * 20)))
 
 
