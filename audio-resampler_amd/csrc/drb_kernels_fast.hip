@@ -40,9 +40,9 @@ namespace
 {
 
 constexpr int kMaxThreads = 320;     // four or five waves, whichever deals the row blocks out more evenly
-constexpr int kBankRowStride = 65;
+constexpr int kBankRowStride = 65;    // floats between taps in the LDS copy of the sinc bank
 constexpr int kMaxTypes = 3;         // row-block types a wave keeps sinc coefficients for
-constexpr int kRebuild = 16;         // tiles between exact rebuilds of those coefficients   // floats between taps in the LDS copy of the sinc bank
+constexpr int kRebuild = 32;          // tiles of a stream between exact rebuilds of those coefficients
 
 enum { kSampleF32 = 0, kSampleI16 = 1, kSampleI32 = 2 };
 enum { kPlanar = 0, kInterleaved = 1 };
@@ -265,6 +265,24 @@ __device__ __forceinline__ void write_up
     // the tail of a segment is also the lookback of the next one
     float * const next = rows - 16 * chain.seg_x + 1;
 
+    if (16 * block >= chain.seg_x - chain.look_u && 16 * block + 16 <= chain.seg_x)
+    {
+        rows[0] = acc[0];
+        rows[16] = acc[1];
+        rows[32] = acc[2];
+        rows[48] = acc[3];
+
+        if (lane.column < 15)
+        {
+            next[0] = acc[0];
+            next[16] = acc[1];
+            next[32] = acc[2];
+            next[48] = acc[3];
+        }
+
+        return;
+    }
+
     #pragma unroll
     for (int r = 0; r < 4; r++)
     {
@@ -290,14 +308,12 @@ __device__ __forceinline__ void stage_up
     // row of x[16 block - N] for block 0, this lane's quarter of the 4-tap step
     float const * const origin = buf.x + 16 * (chain.look_x - chain.up_taps) + lane.operand;
 
-    int block = wave;
-
-    for (; block < blocks; block += chain.waves)
+    for (int block = wave; block < blocks; block += chain.waves)
     {
-        float b0 [STEPS];
+        float b [STEPS];
 
-        load_rows<STEPS, 64>(origin + 256 * block, b0);
-        write_up(chain, buf, lane, block, multiply<STEPS>(a, b0));
+        load_rows<STEPS, 64>(origin + 256 * block, b);
+        write_up(chain, buf, lane, block, multiply<STEPS>(a, b));
     }
 }
 
@@ -439,6 +455,49 @@ __device__ __forceinline__ void write_sinc
             return;
         }
 
+        // blocks wholly inside the segment's tail: the same four stores, and
+        // again into the next segment's lookback
+        if (whole && (first >> 1) >= half - chain.look_d)
+        {
+            int const origin = 16 * ((first >> 1) + chain.look_d) + lane.planes;
+            float * const even = buf.d_even + origin, * const odd = buf.d_odd + origin;
+            int const back = 1 - 16 * half;
+            bool const more = lane.column < 15;
+
+            if (first & 1)
+            {
+                odd[0] = acc[0];
+                even[16] = acc[1];
+                odd[16] = acc[2];
+                even[32] = acc[3];
+
+                if (more)
+                {
+                    odd[back] = acc[0];
+                    even[back + 16] = acc[1];
+                    odd[back + 16] = acc[2];
+                    even[back + 32] = acc[3];
+                }
+            }
+            else
+            {
+                even[0] = acc[0];
+                odd[0] = acc[1];
+                even[16] = acc[2];
+                odd[16] = acc[3];
+
+                if (more)
+                {
+                    even[back] = acc[0];
+                    odd[back] = acc[1];
+                    even[back + 16] = acc[2];
+                    odd[back + 16] = acc[3];
+                }
+            }
+
+            return;
+        }
+
         #pragma unroll
         for (int r = 0; r < 4; r++)
         {
@@ -516,18 +575,14 @@ __device__ __forceinline__ void stage_sinc
         int period = max(first - block * chain.periods, 0);
         int const period_end = min(last - block * chain.periods, chain.periods);
 
-        if (period >= period_end) continue;
-
-        float const (& a) [STEPS] = types[i].a;
-
         for (; period < period_end; period++)
         {
-            float b0 [STEPS];
+            float b [STEPS];
             int const row = types[i].first_row + period * chain.period_in;
 
-            load_rows<STEPS, kStride>(sinc_operand<PLANES>(chain, lds, buf, lane, row), b0);
+            load_rows<STEPS, kStride>(sinc_operand<PLANES>(chain, lds, buf, lane, row), b);
             write_sinc<DOWN, PLAIN>(chain, call, tile, buf, lane, target_lane, channel, target_channel_stride,
-                                    16 * block, period * chain.period_out + 16 * block, multiply<STEPS>(a, b0));
+                                    16 * block, period * chain.period_out + 16 * block, multiply<STEPS>(types[i].a, b));
         }
     }
 }
@@ -589,11 +644,11 @@ __device__ __forceinline__ void stage_down
 
     for (; block < blocks; block += chain.waves)
     {
-        float b0 [STEPS];
+        float b [STEPS];
 
-        load_rows<STEPS, 64>(origin + 256 * block, b0);
+        load_rows<STEPS, 64>(origin + 256 * block, b);
         write_down<PLAIN>(chain, call, tile, buf, lane, target_lane, channel, target_channel_stride, block,
-                          multiply<STEPS>(a, b0));
+                          multiply<STEPS>(a, b));
     }
 }
 
@@ -606,7 +661,8 @@ struct Fetch
     float4_t v [FETCH];
 };
 
-// Thread t fetches rows 4 (t >> 4) + (threads / 4) i + {0..3} of segment t & 15 as one
+// Four neighbouring lanes fetch 16 consecutive frames of one segment (thread t:
+// segment (t >> 2) & 15, rows 4 (t & 3) + 16 (t >> 6) + (threads / 4) i + {0..3}) as one
 // dwordx4 from the step's chunk or from the stream's history, whichever holds
 // all four frames.  The loads are unconditional (a group that straddles a seam
 // or an end reads the last history frames instead and is mended when the tile
@@ -618,7 +674,8 @@ __device__ __forceinline__ void fetch_tile
         float const * history, long long source_channel_stride, int channel, Fetch<FETCH> & fetch
     )
 {
-    int const first = base_x + (threadIdx.x & 15) * chain.seg_x + 4 * (threadIdx.x >> 4) - chain.look_x;
+    int const segment = (threadIdx.x >> 2) & 15, group = (threadIdx.x & 3) + 4 * (threadIdx.x >> 6);
+    int const first = base_x + segment * chain.seg_x + 4 * group - chain.look_x;
     int const pass = 16 * chain.waves;   // rows the workgroup fetches per dwordx4 each
     DRB_GLOBAL float const * const source = global_pointer<float const>(call.source) + channel * source_channel_stride;
     DRB_GLOBAL float const * const past =
@@ -645,7 +702,7 @@ __device__ __forceinline__ void store_tile
         float const * history, long long source_channel_stride, int channel, Fetch<FETCH> & fetch
     )
 {
-    int const segment = threadIdx.x & 15, group = threadIdx.x >> 4;
+    int const segment = (threadIdx.x >> 2) & 15, group = (threadIdx.x & 3) + 4 * (threadIdx.x >> 6);
     int const rows = chain.seg_x + chain.look_x;
     int const first = base_x + segment * chain.seg_x + 4 * group - chain.look_x;
     int const pass = 16 * chain.waves;
@@ -814,8 +871,11 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_fast_kernel
 
     Sinc_Type<SINC_STEPS> types [kMaxTypes];
     Sinc_Anchor anchor = { 0, 0, 0, 0 };
+    // of this workgroup's tiles, which lie tile_stride apart
+    int const rebuild_every = max(1, kRebuild / tile_stride);
+
     float applied_drift = 0.0f;
-    int since_build = kRebuild;
+    int since_build = rebuild_every;
     Fetch<FETCH> fetch;
 
     // Places tile `index`: from the exact phase every kRebuild tiles, by whole
@@ -831,37 +891,39 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_fast_kernel
         tile.base_y = index * chain.tile_frames - chain.seg_y;
         tile.base_s = (DOWN_STEPS ? 2 * tile.base_y : tile.base_y) - delay_behind;
         tile.inside = tile.base_y + 16 * chain.seg_y <= call.target_frames;
-        tile.rebuild = since_build >= kRebuild;
+        tile.rebuild = since_build >= rebuild_every;
         tile.drift = 0.0f;
 
         if (tile.rebuild)
         {
-            // window ends of the middle segment (8) define the phases of all segments
+            // The coefficients are built for the tile half way to the next
+            // rebuild, so that the drift they follow is at most half as long.
+            // Window ends of that tile's middle segment (8) define the phases
+            // of all segments.
+            int const anchor_y = (index + (rebuild_every / 2) * tile_stride) * chain.tile_frames - chain.seg_y;
+            int const anchor_s = (DOWN_STEPS ? 2 * anchor_y : anchor_y) - delay_behind;
             int consumed;
             double unused;
-            long long const phase = call.phase + static_cast<long long>(tile.base_s + 8 * chain.seg_s) * chain.target_delta;
+            long long const phase = call.phase + static_cast<long long>(anchor_s + 8 * chain.seg_s) * chain.target_delta;
 
             sinc_position(phase, chain.source_delta, chain.scale, chain.sinc_pull, consumed, unused);
 
             // the first row's window ends at row -2 or -1 (so that the last row's
             // window still ends inside the segment); the producer-side index must
             // be even when an up-sampler feeds the stage
-            tile.base_u = consumed - 8 * chain.seg_u + 2;
+            anchor.base_u = consumed - 8 * chain.seg_u + 2;
 
-            if (UP_STEPS && ((tile.base_u - delay_front) & 1)) tile.base_u -= 1;
+            if (UP_STEPS && ((anchor.base_u - delay_front) & 1)) anchor.base_u -= 1;
 
-            tile.base_x = UP_STEPS ? (tile.base_u - delay_front) / 2 : tile.base_u - delay_front;
-
+            anchor.base_x = UP_STEPS ? (anchor.base_u - delay_front) / 2 : anchor.base_u - delay_front;
             anchor.rest = phase - static_cast<long long>(consumed) * chain.source_delta;
-            anchor.base_s = tile.base_s;
-            anchor.base_u = tile.base_u;
-            anchor.base_x = tile.base_x;
+            anchor.base_s = anchor_s;
             since_build = 0;
         }
-        else
+
+        // tiles lie whole periods from the anchor on every edge, and the phase's
+        // departure from that is the drift the coefficients follow
         {
-            // between rebuilds every edge advances by whole periods, and the
-            // phase's departure from that is the drift the coefficients follow
             int const tiles = (tile.base_s - anchor.base_s) / tile_advance_s;
 
             tile.base_u = anchor.base_u + tiles * 15 * chain.seg_u;
@@ -907,6 +969,26 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_fast_kernel
 
         STAMP(2);
 
+        int const next_index = tile.index + tile_stride;
+        bool const more = next_index * chain.tile_frames < call.target_frames;
+        Tile next = tile;
+        Sinc_Anchor const build_anchor = anchor;   // placing the next tile may move the anchor on
+
+        // The next tile's source travels while this one is filtered (from memory
+        // that nobody has touched before, it takes microseconds).  Fetching and
+        // storing happen whether or not a tile follows (the last one fetches its own rows
+        // again): every load then meets its wait within the iteration, and none
+        // looks pending when the loop comes round to load into the same registers.
+        if (more) next = place(next_index);
+
+        if (PLAIN && !ABLATED(1))
+        {
+            fetch_tile(chain, call, next.base_x, stream_history, source_channel_stride, channel, fetch);
+            next.fetched = true;
+        }
+
+        STAMP(10);
+
         if (tile.rebuild && !ABLATED(4))
         {
             // The coefficient bank of the fractional stage comes to LDS as
@@ -932,7 +1014,7 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_fast_kernel
             {
                 if (first_block + i < chain.blocks && i < chain.types_per_wave)
                 {
-                    build_sinc_type<SINC_STEPS>(chain, call, anchor, buf.bank, first_block + i, types[i], fault_flag);
+                    build_sinc_type<SINC_STEPS>(chain, call, build_anchor, buf.bank, first_block + i, types[i], fault_flag);
                 }
             }
 
@@ -943,11 +1025,6 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_fast_kernel
 
         STAMP(4);
 
-        int const next_index = tile.index + tile_stride;
-        bool const more = next_index * chain.tile_frames < call.target_frames;
-        Tile next = tile;
-
-        STAMP(3);
 
         if (UP_STEPS > 0)
         {
@@ -966,21 +1043,6 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_fast_kernel
             STAMP(6);
         }
 
-        // The next tile's source travels while this one is filtered.  Asked for
-        // here rather than earlier: loads queue behind the stores of the previous
-        // tile's down-sampler, which by now have long gone.  Fetching and storing
-        // happen whether or not a tile follows (the last one fetches its own rows
-        // again): every load then meets its wait within the iteration, and none
-        // looks pending when the loop comes round to load into the same registers.
-        if (more) next = place(next_index);
-
-        if (PLAIN && !ABLATED(1))
-        {
-            fetch_tile(chain, call, next.base_x, stream_history, source_channel_stride, channel, fetch);
-            next.fetched = true;
-        }
-
-        STAMP(10);
 
         // coefficients follow the phase from the previous tile's to this tile's
         {
@@ -1021,6 +1083,8 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_fast_kernel
         {
             store_tile(chain, call, buf, next.base_x, stream_history, source_channel_stride, channel, fetch);
         }
+
+        STAMP(3);
 
         if (DOWN_STEPS > 0 && !ABLATED(8))
         {

@@ -198,7 +198,21 @@ def main():
     else:
         roofline = {"bound": "hbm", "achieved": round(nbytes / (mean_ms * 1e-3) / 1e9, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(memory_frac, 4)}
-    roofline.update({"traffic": None, "kernel": "drb_cascade_kernel", "kernel_ms": round(mean_ms, 4),
+    fast = args.arithmetic == "fast" and bool(info.fast_path)
+
+    # HBM bytes per launch cannot be counted from inside this process: they come
+    # from the committed rocprofv3 --pmc passes of this same command, if any
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as handle:
+            entry = json.load(handle).get("%s/%s/%d/%.1f" % (args.workload, args.arithmetic, streams, args.seconds))
+        if entry:
+            traffic = entry["bytes_per_launch"]
+    except OSError:
+        pass
+
+    roofline.update({"traffic": traffic, "kernel": "drb_fast_kernel" if fast else "drb_cascade_kernel",
+                     "kernel_ms": round(mean_ms, 4),
                      "algorithmic_flops_per_sample": round(info.flops_per_output_sample, 1),
                      "algorithmic_bytes_per_sample": round(info.bytes_per_output_sample, 3),
                      "other_roofline_frac": round(min(compute_frac, memory_frac), 4)})
@@ -215,7 +229,8 @@ def main():
                                    % (streams, ch, sample, src, dst, ["poor", "fine", "good", "best"][quality],
                                       "pull" if direction else "push", layout, args.seconds, args.arithmetic),
                        "name": args.workload, "streams_per_gpu": streams, "frames_per_step": frames,
-                       "tile_frames": info.tile_frames, "history_frames": info.history_frames},
+                       "tile_frames": info.fast_tile_frames if fast else info.tile_frames,
+                       "history_frames": info.history_frames},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -15,7 +15,7 @@ import torch
 
 import drbamd
 
-PHASES = ["top", "load_x", "wait_b0", "misc", "build", "up", "wait_b1", "sinc", "wait_b2", "down", "prefetch"]
+PHASES = ["top", "load_x", "wait_b0", "store_x", "build", "up", "wait_b1", "sinc", "wait_b2", "down", "prefetch"]
 
 
 def main():
