@@ -221,7 +221,6 @@ struct Tile
     float drift;     // sub-sample position now minus at the last exact build
     bool rebuild;    // sinc coefficients are rebuilt from the exact phase for this tile
     bool inside;     // all 16 segments end before the stream's last target frame
-    bool fetched;    // its source rows are in registers already
 };
 
 struct Buffers
@@ -524,6 +523,16 @@ __device__ __forceinline__ void write_sinc
             return;
         }
 
+        if (whole && tile.inside)
+        {
+            int const frame = tile.base_y + lane.column * chain.seg_y + first + 4 * lane.quad;
+
+            #pragma unroll
+            for (int r = 0; r < 4; r++) target_frame<PLAIN>(chain, call, target_channel_stride, channel, frame + r, acc[r]);
+
+            return;
+        }
+
         #pragma unroll
         for (int r = 0; r < 4; r++)
         {
@@ -612,6 +621,16 @@ __device__ __forceinline__ void write_down
         return;
     }
 
+    if (tile.inside && 16 * block + 16 <= chain.seg_y)
+    {
+        int const frame = tile.base_y + lane.column * chain.seg_y + 16 * block + 4 * lane.quad;
+
+        #pragma unroll
+        for (int r = 0; r < 4; r++) target_frame<PLAIN>(chain, call, target_channel_stride, channel, frame + r, value[r]);
+
+        return;
+    }
+
     #pragma unroll
     for (int r = 0; r < 4; r++)
     {
@@ -654,29 +673,50 @@ __device__ __forceinline__ void stage_down
 
 // ---- source tile: global -> registers -> LDS -------------------------------------------
 
-// FETCH float4 per thread: up to (threads / 4) FETCH rows of 16 segments
-template <int FETCH>
+// What a thread holds of the next tile: FETCH groups of four consecutive
+// frames, (threads / 4) rows apart -- up to (threads / 4) FETCH rows of 16
+// segments per workgroup.  Planar float32 sources travel as the floats they
+// are; other sample types and layouts as four raw samples per group plus the
+// four floats of history that may stand in their place.
+template <int FETCH, bool PLAIN>
 struct Fetch
 {
-    float4_t v [FETCH];
+    float4_t v [FETCH];                    // PLAIN: the frames; else: from the history
+    int raw [PLAIN ? 1 : FETCH][4];        // else: from the step's chunk, unconverted
 };
 
+__device__ __forceinline__ long long chunk_index
+    (
+        Drb_Fast_Chain const & chain, long long channel_stride, int channel, int frame
+    )
+{
+    return chain.layout == kInterleaved ? static_cast<long long>(frame) * chain.channels + channel
+                                        : channel * channel_stride + frame;
+}
+
+__device__ __forceinline__ float raw_sample (int raw, int type)
+{
+    return type == kSampleI16 ? static_cast<float>(raw) * (1.0f / 32768.0f)
+         : type == kSampleI32 ? static_cast<float>(raw) * (1.0f / 2147483648.0f)
+         : __int_as_float(raw);
+}
+
 // Four neighbouring lanes fetch 16 consecutive frames of one segment (thread t:
-// segment (t >> 2) & 15, rows 4 (t & 3) + 16 (t >> 6) + (threads / 4) i + {0..3}) as one
-// dwordx4 from the step's chunk or from the stream's history, whichever holds
-// all four frames.  The loads are unconditional (a group that straddles a seam
-// or an end reads the last history frames instead and is mended when the tile
-// is stored), so that nothing waits for them before then.
-template <int FETCH>
+// segment (t >> 2) & 15, rows 4 (t & 3) + 16 (t >> 6) + (threads / 4) i + {0..3}), a
+// dwordx4 per group from the step's chunk or from the stream's history,
+// whichever holds all four frames.  The loads are unconditional (a group that
+// straddles a seam or an end reads the last history frames instead and is
+// mended when the tile is stored), so that nothing waits for them before then.
+template <int FETCH, bool PLAIN>
 __device__ __forceinline__ void fetch_tile
     (
         Drb_Fast_Chain const & chain, Drb_Device_Call const & call, int base_x,
-        float const * history, long long source_channel_stride, int channel, Fetch<FETCH> & fetch
+        float const * history, long long source_channel_stride, int channel, Fetch<FETCH, PLAIN> & fetch
     )
 {
     int const segment = (threadIdx.x >> 2) & 15, group = (threadIdx.x & 3) + 4 * (threadIdx.x >> 6);
     int const first = base_x + segment * chain.seg_x + 4 * group - chain.look_x;
-    int const pass = 16 * chain.waves;   // rows the workgroup fetches per dwordx4 each
+    int const pass = 16 * chain.waves;   // rows the workgroup fetches per group of four each
     DRB_GLOBAL float const * const source = global_pointer<float const>(call.source) + channel * source_channel_stride;
     DRB_GLOBAL float const * const past =
         global_pointer<float const>(reinterpret_cast<unsigned long long>(history)) + channel * chain.history + chain.history;
@@ -689,17 +729,39 @@ __device__ __forceinline__ void fetch_tile
         int const frame = first + pass * i;
         bool const in_chunk = frame >= 0 && frame + 4 <= call.source_frames;
         bool const in_past = frame + 4 <= 0 && frame >= -chain.history;
-        DRB_GLOBAL float const * const from = in_chunk ? source + frame : past + (in_past ? frame : -4);
 
-        fetch.v[i] = *reinterpret_cast<DRB_GLOBAL float4_unaligned const *>(from);
+        if (PLAIN)
+        {
+            DRB_GLOBAL float const * const from = in_chunk ? source + frame : past + (in_past ? frame : -4);
+
+            fetch.v[i] = *reinterpret_cast<DRB_GLOBAL float4_unaligned const *>(from);
+        }
+        else
+        {
+            fetch.v[i] = *reinterpret_cast<DRB_GLOBAL float4_unaligned const *>(past + (in_past ? frame : -4));
+
+            // the chunk's samples one by one, at frames bent into the chunk
+            if (call.source_frames > 0)
+            {
+                #pragma unroll
+                for (int e = 0; e < 4; e++)
+                {
+                    int const bent = min(max(frame + e, 0), call.source_frames - 1);
+                    long long const index = chunk_index(chain, source_channel_stride, channel, bent);
+
+                    fetch.raw[i][e] = chain.sample_type == kSampleI16 ? static_cast<int>(global_pointer<short const>(call.source)[index])
+                                                                      : global_pointer<int const>(call.source)[index];
+                }
+            }
+        }
     }
 }
 
-template <int FETCH>
+template <int FETCH, bool PLAIN>
 __device__ __forceinline__ void store_tile
     (
         Drb_Fast_Chain const & chain, Drb_Device_Call const & call, Buffers const & buf, int base_x,
-        float const * history, long long source_channel_stride, int channel, Fetch<FETCH> & fetch
+        float const * history, long long source_channel_stride, int channel, Fetch<FETCH, PLAIN> & fetch
     )
 {
     int const segment = (threadIdx.x >> 2) & 15, group = (threadIdx.x & 3) + 4 * (threadIdx.x >> 6);
@@ -715,60 +777,50 @@ __device__ __forceinline__ void store_tile
         // it: no load may look pending once the tile is stored
         asm volatile ("" : "+v"(fetch.v[i]));
 
+        if (!PLAIN)
+        {
+            #pragma unroll
+            for (int e = 0; e < 4; e++) asm volatile ("" : "+v"(fetch.raw[i][e]));
+        }
+
         if (pass * i >= rows) continue;
 
-        // groups of four frames across a seam or an end: one by one
+        int const frame = first + pass * i;
+        bool const in_chunk = frame >= 0 && frame + 4 <= call.source_frames;
+        bool const in_past = frame + 4 <= 0 && frame >= -chain.history;
+        float4_t & value = fetch.v[i];
+
+        if (!PLAIN && in_chunk)
         {
-            int const frame = first + pass * i;
-            bool const in_chunk = frame >= 0 && frame + 4 <= call.source_frames;
-            bool const in_past = frame + 4 <= 0 && frame >= -chain.history;
+            #pragma unroll
+            for (int e = 0; e < 4; e++) value[e] = raw_sample(fetch.raw[i][e], chain.sample_type);
+        }
 
-            if (!in_chunk && !in_past)
+        // groups of four frames across a seam or an end: one by one
+        if (!in_chunk && !in_past)
+        {
+            #pragma unroll
+            for (int e = 0; e < 4; e++)
             {
-                #pragma unroll
-                for (int e = 0; e < 4; e++)
-                {
-                    fetch.v[i][e] = source_frame<true>(chain, call, history, source_channel_stride, channel, frame + e);
-                }
-
-                asm volatile ("" : "+v"(fetch.v[i]));   // as above
+                value[e] = source_frame<PLAIN>(chain, call, history, source_channel_stride, channel, frame + e);
             }
+
+            asm volatile ("" : "+v"(value));   // as above
         }
 
         if (pass * i + pass <= rows)
         {
             #pragma unroll
-            for (int e = 0; e < 4; e++) mine[16 * (pass * i + e)] = fetch.v[i][e];
+            for (int e = 0; e < 4; e++) mine[16 * (pass * i + e)] = value[e];
         }
         else
         {
             #pragma unroll
             for (int e = 0; e < 4; e++)
             {
-                if (4 * group + pass * i + e < rows) mine[16 * (pass * i + e)] = fetch.v[i][e];
+                if (4 * group + pass * i + e < rows) mine[16 * (pass * i + e)] = value[e];
             }
         }
-    }
-}
-
-// Stream edges, history, other sample types and layouts: one sample at a time,
-// straight into LDS.
-template <bool PLAIN>
-__device__ __forceinline__ void load_tile_slowly
-    (
-        Drb_Fast_Chain const & chain, Drb_Device_Call const & call, Buffers const & buf, int base_x,
-        float const * history, long long source_channel_stride, int channel
-    )
-{
-    int const rows = chain.seg_x + chain.look_x;
-
-    #pragma unroll 1
-    for (int i = threadIdx.x; i < 16 * rows; i += blockDim.x)
-    {
-        int const segment = i & 15, row = i >> 4;
-
-        buf.x[i] = source_frame<PLAIN>(chain, call, history, source_channel_stride, channel,
-                                       base_x + segment * chain.seg_x + row - chain.look_x);
     }
 }
 
@@ -876,7 +928,7 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_fast_kernel
 
     float applied_drift = 0.0f;
     int since_build = rebuild_every;
-    Fetch<FETCH> fetch;
+    Fetch<FETCH, PLAIN> fetch;
 
     // Places tile `index`: from the exact phase every kRebuild tiles, by whole
     // periods in between.
@@ -885,7 +937,6 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_fast_kernel
         Tile tile;
 
         tile.index = index;
-        tile.fetched = false;
 
         // segment 1 starts at the tile's first target frame
         tile.base_y = index * chain.tile_frames - chain.seg_y;
@@ -943,11 +994,10 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_fast_kernel
     // ---- tiles of this stream and channel ------------------------------------------
     Tile tile = place(first_tile);
 
-    if (PLAIN && !ABLATED(1))
+    if (!ABLATED(1))
     {
         fetch_tile(chain, call, tile.base_x, stream_history, source_channel_stride, channel, fetch);
         store_tile(chain, call, buf, tile.base_x, stream_history, source_channel_stride, channel, fetch);
-        tile.fetched = true;
     }
 
     for (;;)
@@ -957,11 +1007,7 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_fast_kernel
 
         STAMP(0);
 
-        // a tile fetched ahead is in LDS already (see below)
-        if (!tile.fetched && !ABLATED(1))
-        {
-            load_tile_slowly<PLAIN>(chain, call, buf, tile.base_x, stream_history, source_channel_stride, channel);
-        }
+        // the tile's source rows are in LDS already (see below)
 
         STAMP(1);
 
@@ -981,10 +1027,9 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_fast_kernel
         // looks pending when the loop comes round to load into the same registers.
         if (more) next = place(next_index);
 
-        if (PLAIN && !ABLATED(1))
+        if (!ABLATED(1))
         {
             fetch_tile(chain, call, next.base_x, stream_history, source_channel_stride, channel, fetch);
-            next.fetched = true;
         }
 
         STAMP(10);
@@ -1079,7 +1124,7 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_fast_kernel
         // The next tile's rows have long arrived; they go to LDS here rather
         // than at the top of the loop, where waiting for them would also wait
         // for the stores of the down-sampler below.
-        if (PLAIN && !ABLATED(1))
+        if (!ABLATED(1))
         {
             store_tile(chain, call, buf, next.base_x, stream_history, source_channel_stride, channel, fetch);
         }
