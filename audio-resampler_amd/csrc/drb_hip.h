@@ -78,7 +78,7 @@ typedef struct Drb_Fast_Chain
                                                source, sinc input (odd plane when an
                                                up-sampler feeds it), planes of d      */
     int off_x, off_u, off_d_odd, off_d_even; /* LDS float offsets                      */
-    int off_bank;                           /* sinc bank: shares the planes of d where a down-sampler exists */
+    int off_bank;                           /* sinc bank while coefficients are rebuilt: shares the planes of d where a down-sampler exists */
     int off_taps;                           /* half-band taps, zero-padded: up, then down */
     int waves;                              /* waves per workgroup: 4 or 5, whichever deals the row blocks out more evenly */
     int types_per_wave;                     /* row-block types one wave keeps coefficients for */

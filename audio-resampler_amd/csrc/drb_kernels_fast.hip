@@ -40,7 +40,7 @@ namespace
 {
 
 constexpr int kMaxThreads = 320;     // four or five waves, whichever deals the row blocks out more evenly
-constexpr int kBankRowStride = 65;    // floats between taps in the LDS copy of the sinc bank
+constexpr int kBankTapStride = 65;    // floats between taps in the LDS copy of the sinc bank
 constexpr int kMaxTypes = 3;         // row-block types a wave keeps sinc coefficients for
 constexpr int kRebuild = 32;          // tiles of a stream between exact rebuilds of those coefficients
 
@@ -335,14 +335,23 @@ struct Sinc_Anchor
     int base_s, base_u, base_x;
 };
 
-template <int STEPS>
-__device__ __forceinline__ void build_sinc_type
+// Where a lane's row of a block type sits at the anchor tile, and how its
+// bank rows blend.
+struct Sinc_Spot
+{
+    int first_row, skew;       // window = rows [first_row + skew, first_row + skew + taps)
+    float const * rows;        // bank row of the blend's integer part in the LDS copy, [tap][row]
+    float w [4], v [4];        // weights of bank rows 0 .. 3 from there, and their derivatives
+};
+
+template <int STEPS, bool CUBIC>
+__device__ __forceinline__ void spot_sinc_type
     (
         Drb_Fast_Chain const & chain, Drb_Device_Call const & call, Sinc_Anchor const & anchor,
-        float const * bank, int block, Sinc_Type<STEPS> & type, int * fault_flag
+        float const * bank, int block, Sinc_Spot & spot, int * fault_flag
     )
 {
-    int const lane = threadIdx.x & 63, column = lane & 15, quad = lane >> 4;
+    int const column = threadIdx.x & 15;
     int const taps = chain.sinc_taps;
 
     // exact position of this lane's row in the middle segment (8)
@@ -353,65 +362,125 @@ __device__ __forceinline__ void build_sinc_type
                   chain.source_delta, chain.scale, chain.sinc_pull, consumed, blend);
 
     int const end = consumed - (anchor.base_u + 8 * chain.seg_u);   // window = rows [end - taps, end)
-    int const first_row = __builtin_amdgcn_readfirstlane(end) - taps;
-    int const skew = end - taps - first_row;
 
-    if (column == 15 && skew + taps > 4 * STEPS) atomicOr(fault_flag, 8);
+    spot.first_row = __builtin_amdgcn_readfirstlane(end) - taps;
+    spot.skew = end - taps - spot.first_row;
 
-    float const rows_per_unit = chain.sinc_cubic ? 29.0f : 63.0f;
-    double const scaled = blend * static_cast<double>(rows_per_unit);
+    if (column == 15 && spot.skew + taps > 4 * STEPS) atomicOr(fault_flag, 8);
+
+    double const scaled = blend * (CUBIC ? 29.0 : 63.0);
     int const bank_row = static_cast<int>(scaled);
     float const b = static_cast<float>(scaled - static_cast<double>(bank_row));
-    float const * const rows = bank + bank_row;
 
-    // weights of the bank rows and their derivatives with respect to b
-    float w0, w1, w2 = 0.0f, w3 = 0.0f, v0, v1, v2 = 0.0f, v3 = 0.0f;
+    spot.rows = bank + bank_row;
 
-    if (chain.sinc_cubic)
+    if (CUBIC)
     {
         // Catmull-Rom (drb-audio-converter.c:861-874)
         float const b2 = b * b, b3 = b2 * b;
 
-        w0 = -0.5f * b + b2 - 0.5f * b3;
-        w1 = 1.0f - 2.5f * b2 + 1.5f * b3;
-        w2 = 0.5f * b + 2.0f * b2 - 1.5f * b3;
-        w3 = -0.5f * b2 + 0.5f * b3;
-        v0 = -0.5f + 2.0f * b - 1.5f * b2;
-        v1 = -5.0f * b + 4.5f * b2;
-        v2 = 0.5f + 4.0f * b - 4.5f * b2;
-        v3 = -b + 1.5f * b2;
+        spot.w[0] = -0.5f * b + b2 - 0.5f * b3;
+        spot.w[1] = 1.0f - 2.5f * b2 + 1.5f * b3;
+        spot.w[2] = 0.5f * b + 2.0f * b2 - 1.5f * b3;
+        spot.w[3] = -0.5f * b2 + 0.5f * b3;
+        spot.v[0] = -0.5f + 2.0f * b - 1.5f * b2;
+        spot.v[1] = -5.0f * b + 4.5f * b2;
+        spot.v[2] = 0.5f + 4.0f * b - 4.5f * b2;
+        spot.v[3] = -b + 1.5f * b2;
     }
     else
     {
-        w0 = 1.0f - b;
-        w1 = b;
-        v0 = -1.0f;
-        v1 = 1.0f;
+        spot.w[0] = 1.0f - b;
+        spot.w[1] = b;
+        spot.w[2] = spot.w[3] = 0.0f;
+        spot.v[0] = -1.0f;
+        spot.v[1] = 1.0f;
+        spot.v[2] = spot.v[3] = 0.0f;
+    }
+}
+
+// Coefficients of up to kMaxTypes block types at once, from the copy of the
+// bank in LDS (a gather of 64 different entries per instruction, which LDS
+// takes in its stride and the vector memory path does not): the bank rows of
+// all types are asked for before the first is used, in four parts for the
+// cubic bank, which needs twice the registers.
+template <int STEPS, bool CUBIC>
+__device__ __forceinline__ void build_sinc_types
+    (
+        Drb_Fast_Chain const & chain, Drb_Device_Call const & call, Sinc_Anchor const & anchor,
+        float const * bank, int first_block, int count, Sinc_Type<STEPS> (& types) [kMaxTypes], int * fault_flag
+    )
+{
+    constexpr int kReach = CUBIC ? 4 : 2;
+    constexpr int kHalves = CUBIC ? 4 : 1;
+    constexpr int kHalf = (STEPS + kHalves - 1) / kHalves;
+
+    int const quad = (threadIdx.x & 63) >> 4;
+    int const taps = chain.sinc_taps;
+    float const rows_per_unit = CUBIC ? 29.0f : 63.0f;
+    Sinc_Spot spots [kMaxTypes];
+
+    #pragma unroll
+    for (int i = 0; i < kMaxTypes; i++)
+    {
+        // (types past the wave's run are placed like its last one: harmless, and
+        // every lane keeps to one path)
+        int const block = min(first_block + min(i, count - 1), chain.blocks - 1);
+
+        spot_sinc_type<STEPS, CUBIC>(chain, call, anchor, bank, block, spots[i], fault_flag);
     }
 
     #pragma unroll
-    for (int s = 0; s < STEPS; s++)
+    for (int half = 0; half < kHalves; half++)
     {
-        int const t = 4 * s + quad - skew;
-        bool const live = t >= 0 && t < taps;
-        float const * const k = rows + (live ? t : 0) * kBankRowStride;
-        float value = w0 * k[0] + w1 * k[1];
-        float slope = v0 * k[0] + v1 * k[1];
+        float k [kMaxTypes][kHalf][kReach];
 
-        if (chain.sinc_cubic)
+        #pragma unroll
+        for (int i = 0; i < kMaxTypes; i++)
         {
-            value += w2 * k[2] + w3 * k[3];
-            slope += v2 * k[2] + v3 * k[3];
+            #pragma unroll
+            for (int n = 0; n < kHalf; n++)
+            {
+                int const t = 4 * (half * kHalf + n) + quad - spots[i].skew;
+                int const tap = t >= 0 && t < taps ? t : 0;
+
+                #pragma unroll
+                for (int j = 0; j < kReach; j++) k[i][n][j] = spots[i].rows[tap * kBankTapStride + j];
+            }
         }
 
-        type.a[s] = live ? value : 0.0f;
+        #pragma unroll
+        for (int i = 0; i < kMaxTypes; i++)
+        {
+            #pragma unroll
+            for (int n = 0; n < kHalf; n++)
+            {
+                int const s = half * kHalf + n;
 
-        unsigned const rounded = (__float_as_uint(live ? slope * rows_per_unit : 0.0f) + 0x8000u) >> 16;
+                if (s >= STEPS) continue;
 
-        if (s & 1) type.g[s / 2] |= rounded << 16; else type.g[s / 2] = rounded;
+                int const t = 4 * s + quad - spots[i].skew;
+                bool const live = t >= 0 && t < taps;
+                float value = 0.0f, slope = 0.0f;
+
+                #pragma unroll
+                for (int j = 0; j < kReach; j++)
+                {
+                    value = fmaf(spots[i].w[j], k[i][n][j], value);
+                    slope = fmaf(spots[i].v[j], k[i][n][j], slope);
+                }
+
+                types[i].a[s] = live ? value : 0.0f;
+
+                unsigned const rounded = (__float_as_uint(live ? slope * rows_per_unit : 0.0f) + 0x8000u) >> 16;
+
+                if (s & 1) types[i].g[s / 2] |= rounded << 16; else types[i].g[s / 2] = rounded;
+            }
+        }
     }
 
-    type.first_row = first_row;
+    #pragma unroll
+    for (int i = 0; i < kMaxTypes; i++) types[i].first_row = spots[i].first_row;
 }
 
 // Rows first .. first + 15 of the sinc output (counted from the segment's
@@ -836,7 +905,7 @@ __device__ __forceinline__ void store_tile
 #  define ABLATED(bit) false
 #endif
 
-template <int UP_STEPS, int SINC_STEPS, int DOWN_STEPS, int FETCH, bool PLAIN>
+template <int UP_STEPS, int SINC_STEPS, int DOWN_STEPS, int FETCH, bool CUBIC, bool PLAIN>
 __global__ __launch_bounds__(kMaxThreads, 3) void drb_fast_kernel
     (
         Drb_Fast_Chain const chain,
@@ -1040,28 +1109,33 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_fast_kernel
             // [tap][row] for the occasion: it may lie where d's planes are,
             // which nobody touches between the barrier above and the next one.
             {
-                int const taps = chain.sinc_taps, rows = chain.sinc_cubic ? 32 : 64;
+                int const shift = chain.sinc_taps == 32 ? 5 : 4;           // 16 or 32 taps
+                int const count = (CUBIC ? 32 : 64) << shift;
                 float const * const source = table_at(chain.sinc_table);
+                float value [8];
 
-                for (int i = threadIdx.x; i < rows * taps; i += blockDim.x)
+                #pragma unroll
+                for (int n = 0; n < 8; n++)
                 {
-                    int const row = i / taps, tap = i - row * taps;
-                    buf.bank[tap * kBankRowStride + row] = source[i];
+                    int const i = threadIdx.x + n * blockDim.x;
+
+                    value[n] = source[min(i, count - 1)];
+                }
+
+                #pragma unroll
+                for (int n = 0; n < 8; n++)
+                {
+                    int const i = threadIdx.x + n * blockDim.x;
+                    int const row = i >> shift, tap = i - (row << shift);
+
+                    if (i < count) buf.bank[tap * kBankTapStride + row] = value[n];
                 }
 
                 __syncthreads();
             }
 
-            int const first_block = first_chain / chain.periods;
-
-            #pragma unroll
-            for (int i = 0; i < kMaxTypes; i++)
-            {
-                if (first_block + i < chain.blocks && i < chain.types_per_wave)
-                {
-                    build_sinc_type<SINC_STEPS>(chain, call, build_anchor, buf.bank, first_block + i, types[i], fault_flag);
-                }
-            }
+            build_sinc_types<SINC_STEPS, CUBIC>(chain, call, build_anchor, buf.bank,
+                                                first_chain / chain.periods, chain.types_per_wave, types, fault_flag);
 
             __syncthreads();   // the bank's place may be written again
 
@@ -1179,20 +1253,21 @@ Fast_Kernel * pick_kernel (Drb_Fast_Chain const * chain)
 
     bool const plain = chain->sample_type == kSampleF32 && chain->layout == kPlanar;
 
-#define DRB_FAST_CASE(KEY, UP, SINC, DOWN, FETCH) \
-      case KEY: if (rows > pass * FETCH) return nullptr; \
-                return plain ? drb_fast_kernel<UP, SINC, DOWN, FETCH, true> : drb_fast_kernel<UP, SINC, DOWN, FETCH, false>;
+#define DRB_FAST_CASE(KEY, UP, SINC, DOWN, FETCH, CUBIC) \
+      case KEY: if (rows > pass * FETCH || (chain->sinc_cubic != 0) != CUBIC) return nullptr; \
+                return plain ? drb_fast_kernel<UP, SINC, DOWN, FETCH, CUBIC, true> \
+                             : drb_fast_kernel<UP, SINC, DOWN, FETCH, CUBIC, false>;
 
     switch (key)
     {
-      DRB_FAST_CASE(141214, 14, 12, 14, 3)   // good, rate going up
-      DRB_FAST_CASE(141314, 14, 13, 14, 4)   // good, rate going down
-      DRB_FAST_CASE(120812, 12, 8, 12, 3)    // fine
-      DRB_FAST_CASE(120912, 12, 9, 12, 3)
-      DRB_FAST_CASE(161216, 16, 12, 16, 4)   // best
-      DRB_FAST_CASE(161316, 16, 13, 16, 4)
-      DRB_FAST_CASE(800, 0, 8, 0, 4)         // poor
-      DRB_FAST_CASE(900, 0, 9, 0, 4)
+      DRB_FAST_CASE(141214, 14, 12, 14, 3, false)   // good, rate going up
+      DRB_FAST_CASE(141314, 14, 13, 14, 4, false)   // good, rate going down
+      DRB_FAST_CASE(120812, 12, 8, 12, 3, true)    // fine
+      DRB_FAST_CASE(120912, 12, 9, 12, 3, true)
+      DRB_FAST_CASE(161216, 16, 12, 16, 4, true)   // best
+      DRB_FAST_CASE(161316, 16, 13, 16, 4, true)
+      DRB_FAST_CASE(800, 0, 8, 0, 4, false)         // poor
+      DRB_FAST_CASE(900, 0, 9, 0, 4, false)
     }
 
 #undef DRB_FAST_CASE

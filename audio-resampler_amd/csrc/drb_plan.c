@@ -738,7 +738,7 @@ int drb_plan_fast_geometry (Drb_Plan const * plan, int lds_budget_bytes, Drb_Fas
         offset += (chain->seg_s / 2 + chain->look_d) * 16;
     }
 
-    /* The bank, [tap][row] with 65 floats between taps, is only read while
+    /* The sinc bank, [tap][row] with 65 floats between taps, is only read while
      * coefficients are rebuilt, when the planes of d are idle: it shares them. */
     {
         int const bank = taps * 65 + 8;
