@@ -81,6 +81,7 @@ typedef struct Drb_Fast_Chain
     int off_bank;                           /* sinc bank while coefficients are rebuilt: shares the planes of d where a down-sampler exists */
     int off_taps;                           /* half-band taps, zero-padded: up, then down */
     int waves;                              /* waves per workgroup: 4 or 5, whichever deals the row blocks out more evenly */
+    float column_drift;                     /* sub-sample position of segment c minus segment c - 1 (0: too small to matter) */
     int types_per_wave;                     /* row-block types one wave keeps coefficients for */
     int lds_floats;
     int tile_frames;                        /* target frames per tile = 15 * seg_y    */

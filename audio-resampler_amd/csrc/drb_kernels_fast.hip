@@ -659,8 +659,34 @@ __device__ __forceinline__ void stage_sinc
             int const row = types[i].first_row + period * chain.period_in;
 
             load_rows<STEPS, kStride>(sinc_operand<PLANES>(chain, lds, buf, lane, row), b);
+
+            float4_t acc = multiply<STEPS>(types[i].a, b);
+
+            // Where the phase differs noticeably from segment to segment, every
+            // segment (column) adds its own first-order term: the same product
+            // with the coefficients' derivatives, times its distance from the
+            // middle segment, whose phase the coefficients have.
+            if (chain.column_drift != 0.0f)
+            {
+                float slope [STEPS];
+
+                #pragma unroll
+                for (int s = 0; s < STEPS; s++)
+                {
+                    unsigned const pair = types[i].g[s / 2];
+
+                    slope[s] = __uint_as_float((s & 1) ? pair & 0xffff0000u : pair << 16);
+                }
+
+                float4_t const tilt = multiply<STEPS>(slope, b);
+                float const away = static_cast<float>(lane.column - 8) * chain.column_drift;
+
+                #pragma unroll
+                for (int r = 0; r < 4; r++) acc[r] = fmaf(away, tilt[r], acc[r]);
+            }
+
             write_sinc<DOWN, PLAIN>(chain, call, tile, buf, lane, target_lane, channel, target_channel_stride,
-                                    16 * block, period * chain.period_out + 16 * block, multiply<STEPS>(types[i].a, b));
+                                    16 * block, period * chain.period_out + 16 * block, acc);
         }
     }
 }

@@ -636,8 +636,10 @@ int drb_plan_fast_geometry (Drb_Plan const * plan, int lds_budget_bytes, Drb_Fas
 
     int const period_out = (int)(ratio_out * multiple), period_in = (int)(ratio_in * multiple);
 
-    /* segment: whole periods, about 320 target frames, halvable where a 2x stage follows */
-    int periods = (320 + period_out / 2) / period_out;
+    /* segment: whole periods, about 320 outputs of the sinc stage (160 where it
+     * stands alone and outputs are target frames), halvable where a 2x stage follows */
+    int const aim = up >= 0 || down >= 0 ? 320 : 160;
+    int periods = (aim + period_out / 2) / period_out;
 
     if (periods < 1) periods = 1;
 
@@ -705,7 +707,12 @@ int drb_plan_fast_geometry (Drb_Plan const * plan, int lds_budget_bytes, Drb_Fas
     double const drift = ((double)plan->target_delta - exact) / (double)plan->source_delta;
     double const worst = 7.5 * chain->seg_s * (drift < 0 ? -drift : drift);
 
-    if (worst > 1.0e-7) return 0;
+    /* beyond the accuracy budget the kernel adds a first-order term per segment
+     * (a second product with the coefficients' derivatives); that one is good
+     * for far more than any of the 13 x 13 rate pairs needs */
+    if (worst > 2.0e-6) return 0;
+
+    chain->column_drift = worst > 1.0e-7 ? (float)(chain->seg_s * drift) : 0.0f;
 
     /* LDS map.  Every buffer is [row][16 segments]; a row is 16 floats, so
      * consecutive rows alternate between the two halves of the 32 banks.  In
