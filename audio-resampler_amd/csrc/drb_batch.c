@@ -19,7 +19,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-enum { ring_slots = 4, max_step_frames = 1 << 24, fault_words = 128 };
+enum { ring_slots = 4, max_step_frames = 1 << 24, fault_words = 128, host_slots = 3 };
 
 struct DrbAmd_Batch
 {
@@ -39,6 +39,7 @@ struct DrbAmd_Batch
     int * dense_frames;
     int * dense_capacity;
     int * dense_produced;
+    int * feed_counts;                /* host scratch for the host-fed entry   */
 
     float * history [2];              /* device, [stream][channel][history]    */
     int history_current;
@@ -51,6 +52,12 @@ struct DrbAmd_Batch
 
     int * fault_device;
     int * fault_host;                 /* pinned                                */
+
+    /* host-fed entry: three slices of streams in flight */
+    void * feed_streams [3];          /* copy in, convert, copy out            */
+    void * feed_source [host_slots], * feed_target [host_slots];   /* device   */
+    size_t feed_source_bytes, feed_target_bytes;                   /* per slot */
+    void * feed_in [host_slots], * feed_done [host_slots], * feed_out [host_slots]; /* events */
 
     int timing;                       /* bracket the cascade kernel with events */
     void * kernel_start, * kernel_stop;
@@ -204,6 +211,19 @@ DrbAmd_Status drb_amd_plan_info (DrbAmd_Batch_Config const * config, DrbAmd_Plan
     drb_plan_fast_geometry(&plan, fast_lds_budget, &fast);
     info->fast_path = fast.usable && drb_hip_fast_kernel_exists(&fast);
     info->fast_tile_frames = fast.tile_frames;
+    info->fast_issued_flops_per_output_sample = 0.0;
+
+    if (info->fast_path)
+    {
+        /* 16 x 16 x 4 products of 2048 flop each, per tile of one channel */
+        long const up_blocks = fast.has_up ? (fast.seg_x + 15) / 16 : 0;
+        long const down_blocks = fast.has_down ? (fast.seg_y + 15) / 16 : 0;
+        long const products = up_blocks * ((fast.up_taps + 16) / 4)
+                            + (long)fast.blocks * fast.periods * fast.ksteps * (fast.column_drift != 0.0f ? 2 : 1)
+                            + down_blocks * ((fast.down_taps + 16) / 4);
+
+        info->fast_issued_flops_per_output_sample = 2048.0 * (double)products / (double)fast.tile_frames;
+    }
 
     return drb_amd_ok;
 }
@@ -260,6 +280,17 @@ static void release (DrbAmd_Batch * batch)
         if (batch->calls_host[i]) drb_hip_host_free(batch->calls_host[i]);
     }
 
+    for (int i = 0; i < host_slots; i++)
+    {
+        if (batch->feed_source[i]) drb_hip_free(batch->feed_source[i]);
+        if (batch->feed_target[i]) drb_hip_free(batch->feed_target[i]);
+        if (batch->feed_in[i]) drb_hip_event_destroy(batch->feed_in[i]);
+        if (batch->feed_done[i]) drb_hip_event_destroy(batch->feed_done[i]);
+        if (batch->feed_out[i]) drb_hip_event_destroy(batch->feed_out[i]);
+    }
+
+    for (int i = 0; i < 3; i++) if (batch->feed_streams[i]) drb_hip_stream_destroy(batch->feed_streams[i]);
+
     if (batch->kernel_start) drb_hip_event_destroy(batch->kernel_start);
     if (batch->kernel_stop) drb_hip_event_destroy(batch->kernel_stop);
     if (batch->history[0]) drb_hip_free(batch->history[0]);
@@ -276,6 +307,7 @@ static void release (DrbAmd_Batch * batch)
     free(batch->dense_frames);
     free(batch->dense_capacity);
     free(batch->dense_produced);
+    free(batch->feed_counts);
     free(batch);
 }
 
@@ -340,9 +372,11 @@ DrbAmd_Status drb_amd_batch_create (DrbAmd_Batch_Config const * config, DrbAmd_B
     batch->dense_frames = calloc(n, sizeof(int));
     batch->dense_capacity = calloc(n, sizeof(int));
     batch->dense_produced = calloc(n, sizeof(int));
+    batch->feed_counts = calloc(n, sizeof(int));
 
     if (!batch->states || !batch->trial_states || !batch->steps || !batch->dense_source
-        || !batch->dense_target || !batch->dense_frames || !batch->dense_capacity || !batch->dense_produced)
+        || !batch->dense_target || !batch->dense_frames || !batch->dense_capacity || !batch->dense_produced
+        || !batch->feed_counts)
     {
         release(batch);
         return fail(drb_amd_error_out_of_memory, "out of host memory");
@@ -609,6 +643,148 @@ DrbAmd_Status drb_amd_batch_process_dense
         batch->dense_target, target_channel_stride, pull ? batch->dense_frames : batch->dense_capacity,
         produced_each ? produced_each : batch->dense_produced, hip_stream
     );
+}
+
+/* ---- host-fed: copy in, convert and copy out in overlapping slices ---------- */
+
+static int feed_prepare (DrbAmd_Batch * batch, size_t source_bytes, size_t target_bytes)
+{
+    int code = 0;
+
+    for (int i = 0; i < 3 && !code; i++)
+    {
+        if (!batch->feed_streams[i]) code = drb_hip_stream_create(&batch->feed_streams[i]);
+    }
+
+    for (int i = 0; i < host_slots && !code; i++)
+    {
+        if (!batch->feed_in[i]) code = drb_hip_event_create(&batch->feed_in[i]);
+        if (!code && !batch->feed_done[i]) code = drb_hip_event_create(&batch->feed_done[i]);
+        if (!code && !batch->feed_out[i]) code = drb_hip_event_create(&batch->feed_out[i]);
+    }
+
+    if (!code && source_bytes > batch->feed_source_bytes)
+    {
+        for (int i = 0; i < host_slots && !code; i++)
+        {
+            if (batch->feed_source[i]) drb_hip_free(batch->feed_source[i]);
+            batch->feed_source[i] = 0;
+            code = drb_hip_alloc(&batch->feed_source[i], source_bytes);
+        }
+
+        batch->feed_source_bytes = code ? 0 : source_bytes;
+    }
+
+    if (!code && target_bytes > batch->feed_target_bytes)
+    {
+        for (int i = 0; i < host_slots && !code; i++)
+        {
+            if (batch->feed_target[i]) drb_hip_free(batch->feed_target[i]);
+            batch->feed_target[i] = 0;
+            code = drb_hip_alloc(&batch->feed_target[i], target_bytes);
+        }
+
+        batch->feed_target_bytes = code ? 0 : target_bytes;
+    }
+
+    return code;
+}
+
+DrbAmd_Status drb_amd_batch_process_host_dense
+    (
+        DrbAmd_Batch * batch,
+        void const * source_base, long long source_stream_stride, long long source_channel_stride,
+        void * target_base, long long target_stream_stride, long long target_channel_stride,
+        int frames, int capacity,
+        int * produced_each
+    )
+{
+    if (!batch || !source_base || !target_base || source_stream_stride <= 0 || target_stream_stride <= 0)
+    {
+        return fail(drb_amd_error_bad_argument, "bad argument");
+    }
+
+    int const n = batch->config.stream_count;
+    int const pull = batch->plan.direction == 1;
+    size_t const source_stream_bytes = (size_t)source_stream_stride * batch->sample_bytes;
+    size_t const target_stream_bytes = (size_t)target_stream_stride * batch->sample_bytes;
+
+    /* slices of about 128 MB (smaller ones leave the link half idle: 16 MB
+     * slices reached 25 GB/s where 128 MB ones reach 55), at least four of
+     * them so that the copies of one overlap the conversion of another */
+    char const * const tuned = getenv("DRB_AMD_HOST_SLICE_MB");   /* diagnostic */
+    long long const slice_bytes = (long long)(tuned && atoi(tuned) > 0 ? atoi(tuned) : 128) << 20;
+    long long per_slice = slice_bytes / (long long)(source_stream_bytes + target_stream_bytes);
+
+    if (per_slice > (n + 3) / 4) per_slice = (n + 3) / 4;
+    if (per_slice < 1) per_slice = 1;
+
+    int code = drb_hip_set_device(batch->device);
+
+    if (!code) code = feed_prepare(batch, (size_t)per_slice * source_stream_bytes, (size_t)per_slice * target_stream_bytes);
+    if (code) return fail_hip("host feed set-up", code);
+
+    void * const in = batch->feed_streams[0], * const work = batch->feed_streams[1], * const out = batch->feed_streams[2];
+    int * const produced = produced_each ? produced_each : batch->dense_produced;
+    DrbAmd_Status status = drb_amd_ok;
+    int slice = 0;
+
+    for (int first = 0; first < n && status == drb_amd_ok; first += (int)per_slice, slice++)
+    {
+        int const count = first + per_slice <= n ? (int)per_slice : n - first;
+        int const slot = slice % host_slots;
+
+        /* the slot's buffers are free once the slice that used them is back on the host */
+        if (slice >= host_slots) code = drb_hip_stream_wait_event(in, batch->feed_out[slot]);
+
+        if (!code) code = drb_hip_upload_async(batch->feed_source[slot], (char const *)source_base + (size_t)first * source_stream_bytes,
+                                               (size_t)count * source_stream_bytes, in);
+        if (!code) code = drb_hip_event_record(batch->feed_in[slot], in);
+        if (!code) code = drb_hip_stream_wait_event(work, batch->feed_in[slot]);
+        if (code) { status = fail_hip("host feed upload", code); break; }
+
+        for (int s = 0; s < n; s++)
+        {
+            int const mine = s >= first && s < first + count;
+
+            batch->dense_source[s] = mine ? (char const *)batch->feed_source[slot] + (size_t)(s - first) * source_stream_bytes : 0;
+            batch->dense_target[s] = mine ? (char *)batch->feed_target[slot] + (size_t)(s - first) * target_stream_bytes : 0;
+            batch->dense_frames[s] = mine ? frames : 0;
+            batch->dense_capacity[s] = mine ? capacity : 0;
+        }
+
+        /* (the produced counts of the streams outside the slice come back as 0) */
+        status = drb_amd_batch_process
+        (
+            batch,
+            batch->dense_source, source_channel_stride, pull ? batch->dense_capacity : batch->dense_frames,
+            batch->dense_target, target_channel_stride, pull ? batch->dense_frames : batch->dense_capacity,
+            batch->feed_counts, work
+        );
+
+        if (status != drb_amd_ok) break;
+
+        for (int s = first; s < first + count; s++) produced[s] = batch->feed_counts[s];
+
+        code = drb_hip_event_record(batch->feed_done[slot], work);
+
+        if (!code) code = drb_hip_stream_wait_event(out, batch->feed_done[slot]);
+        if (!code) code = drb_hip_download_async((char *)target_base + (size_t)first * target_stream_bytes, batch->feed_target[slot],
+                                                 (size_t)count * target_stream_bytes, out);
+        if (!code) code = drb_hip_event_record(batch->feed_out[slot], out);
+        if (code) { status = fail_hip("host feed download", code); break; }
+    }
+
+    /* whatever happened, nothing may still be using the caller's memory */
+    int const drained_in = drb_hip_stream_synchronize(in);
+    int const drained_work = drb_hip_stream_synchronize(work);
+    int const drained_out = drb_hip_stream_synchronize(out);
+
+    if (status != drb_amd_ok) return status;
+    if (drained_in || drained_work || drained_out) return fail_hip("host feed", drained_in ? drained_in : drained_work ? drained_work : drained_out);
+    if (*batch->fault_host) return fail(drb_amd_error_device, "kernel range check failed (code %d)", *batch->fault_host);
+
+    return drb_amd_ok;
 }
 
 DrbAmd_Status drb_amd_batch_synchronize (DrbAmd_Batch * batch, void * hip_stream)

@@ -103,6 +103,9 @@ int drb_hip_memset_async (void * pointer, int value, size_t bytes, void * stream
 int drb_hip_upload_async (void * device, void const * host, size_t bytes, void * stream);
 int drb_hip_download_async (void * host, void const * device, size_t bytes, void * stream);
 int drb_hip_stream_synchronize (void * stream);
+int drb_hip_stream_create (void ** stream);
+int drb_hip_stream_destroy (void * stream);
+int drb_hip_stream_wait_event (void * stream, void * event);
 int drb_hip_event_create (void ** event);
 int drb_hip_timing_event_create (void ** event);
 int drb_hip_event_elapsed_ms (float * ms, void * start, void * stop);

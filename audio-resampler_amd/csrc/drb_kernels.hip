@@ -685,6 +685,21 @@ int drb_hip_download_async (void * host, void const * device, size_t bytes, void
 
 int drb_hip_stream_synchronize (void * stream) { return hipStreamSynchronize(static_cast<hipStream_t>(stream)); }
 
+int drb_hip_stream_create (void ** stream)
+{
+    hipStream_t created;
+    hipError_t const status = hipStreamCreateWithFlags(&created, hipStreamNonBlocking);
+    *stream = created;
+    return status;
+}
+
+int drb_hip_stream_destroy (void * stream) { return hipStreamDestroy(static_cast<hipStream_t>(stream)); }
+
+int drb_hip_stream_wait_event (void * stream, void * event)
+{
+    return hipStreamWaitEvent(static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(event), 0);
+}
+
 int drb_hip_event_create (void ** event)
 {
     hipEvent_t created;

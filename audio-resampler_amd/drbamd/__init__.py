@@ -50,7 +50,8 @@ class PlanInfo(ctypes.Structure):
                 ("history_frames", ctypes.c_int), ("tile_frames", ctypes.c_int),
                 ("flops_per_output_sample", ctypes.c_double),
                 ("bytes_per_output_sample", ctypes.c_double),
-                ("fast_path", ctypes.c_int), ("fast_tile_frames", ctypes.c_int)]
+                ("fast_path", ctypes.c_int), ("fast_tile_frames", ctypes.c_int),
+                ("fast_issued_flops_per_output_sample", ctypes.c_double)]
 
     def stages(self):
         kinds = {1: "up2x", 2: "down2x", 3: "sinc", 4: "slicer"}
@@ -73,6 +74,10 @@ lib.drb_amd_batch_process_dense.argtypes = [ctypes.c_void_p,
                                             ctypes.c_void_p, ctypes.c_longlong, ctypes.c_longlong,
                                             ctypes.c_void_p, ctypes.c_longlong, ctypes.c_longlong,
                                             ctypes.c_int, ctypes.c_int, c_int_p, ctypes.c_void_p]
+lib.drb_amd_batch_process_host_dense.argtypes = [ctypes.c_void_p,
+                                                 ctypes.c_void_p, ctypes.c_longlong, ctypes.c_longlong,
+                                                 ctypes.c_void_p, ctypes.c_longlong, ctypes.c_longlong,
+                                                 ctypes.c_int, ctypes.c_int, c_int_p]
 lib.drb_amd_batch_synchronize.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 lib.drb_amd_batch_time_kernels.argtypes = [ctypes.c_void_p, ctypes.c_int]
 lib.drb_amd_batch_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
@@ -185,6 +190,15 @@ class Batch:
                                               ctypes.c_void_p(target_ptr), target_stream_stride,
                                               target_channel_stride, frames, capacity, produced,
                                               ctypes.c_void_p(stream or 0)))
+
+    def process_host_dense(self, source_ptr, source_stream_stride, source_channel_stride,
+                           target_ptr, target_stream_stride, target_channel_stride,
+                           frames, capacity, produced=None):
+        """Buffers in host memory (pinned for speed); returns when the targets are filled."""
+        check(lib.drb_amd_batch_process_host_dense(self.handle, ctypes.c_void_p(source_ptr),
+                                                   source_stream_stride, source_channel_stride,
+                                                   ctypes.c_void_p(target_ptr), target_stream_stride,
+                                                   target_channel_stride, frames, capacity, produced))
 
     def time_kernels(self, enable=True):
         check(lib.drb_amd_batch_time_kernels(self.handle, 1 if enable else 0))

@@ -86,6 +86,33 @@ def cpu_baseline(workload, seconds_budget=12.0):
                       "4096-frame process() calls" % (threads, seconds_budget)}
 
 
+def host_fed(batch, source, ch, source_frames, target_capacity, torch_type, frames, capacity, layout, direction, steps=3):
+    """The same step with sources and targets in pinned host memory: copies in,
+    conversion and copies out overlap in slices of streams.  A side measurement
+    (never `value`): the link, not the kernel, sets this rate."""
+    import torch
+
+    streams = source.shape[0]
+    host_source = source.cpu().pin_memory()
+    host_target = torch.zeros(streams * ch * target_capacity, dtype=torch_type).pin_memory()
+    produced = (ctypes.c_int * streams)()
+
+    def step():
+        batch.process_host_dense(host_source.data_ptr(), ch * source_frames, source_frames,
+                                 host_target.data_ptr(), ch * target_capacity, target_capacity,
+                                 frames, capacity, produced=produced)
+        return (sum(produced) if direction == 0 else frames * streams) * ch
+
+    step()
+    start = time.perf_counter()
+    samples = sum(step() for _ in range(steps))
+    elapsed = time.perf_counter() - start
+    moved = (host_source.numel() * host_source.element_size() + host_target.numel() * host_target.element_size()) * steps
+    return {"value": round(samples / elapsed / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(elapsed / steps * 1e3, 3),
+            "link_GBps": round(moved / elapsed / 1e9, 2),
+            "note": "pinned host buffers, H2D + convert + D2H overlapped in slices (drb_amd_batch_process_host_dense)"}
+
+
 def main():
     parser = argparse.ArgumentParser()
     parser.add_argument("--gpus", type=int, default=1)
@@ -96,6 +123,7 @@ def main():
     parser.add_argument("--seconds", type=float, default=1.0, help="audio seconds per stream per step")
     parser.add_argument("--arithmetic", default="fast", choices=["exact", "fast"])
     parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--no-host-fed", action="store_true", help="skip the PCIe-inclusive side measurement")
     args = parser.parse_args()
 
     import torch
@@ -216,6 +244,12 @@ def main():
                      "algorithmic_flops_per_sample": round(info.flops_per_output_sample, 1),
                      "algorithmic_bytes_per_sample": round(info.bytes_per_output_sample, 3),
                      "other_roofline_frac": round(min(compute_frac, memory_frac), 4)})
+    if fast:
+        # the matrix-core kernel merges upstream's two (or four) dot products per
+        # output into one and pads its banded products: what it really issues
+        issued = info.fast_issued_flops_per_output_sample
+        roofline.update({"issued_flops_per_sample": round(issued, 1),
+                         "issued_mfma_frac": round(issued * mean_samples / (mean_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)})
 
     if rank == 0:
         line = {
@@ -233,6 +267,9 @@ def main():
                        "history_frames": info.history_frames},
             "roofline": roofline,
         }
+        if world == 1 and not args.no_host_fed:
+            line["host_fed"] = host_fed(batch, source, ch, source_frames, target_capacity, torch_type, frames,
+                                        source_frames if direction == 1 else target_capacity, layout, direction)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(WORKLOADS[args.workload])
         print(json.dumps(line), flush=True)

@@ -273,6 +273,22 @@ extern DrbAmd_Status drb_amd_batch_process_dense
         void * hip_stream
     );
 
+/* The same with source and target in HOST memory (pinned memory copies at the
+ * link's speed; pageable memory works, slowly): streams are handed to the
+ * device in slices of about 128 MB, and one slice's copies run while another is
+ * being converted (three internal HIP streams, three slices in flight, staging
+ * buffers owned by the batch and grown on demand).  Blocks until every target
+ * is back in host memory.  No counterpart upstream, whose caller's thread does
+ * the filtering; it is what a host-side data loader calls. */
+extern DrbAmd_Status drb_amd_batch_process_host_dense
+    (
+        DrbAmd_Batch * batch,
+        void const * source_base, long long source_stream_stride, long long source_channel_stride,
+        void * target_base, long long target_stream_stride, long long target_channel_stride,
+        int frames, int capacity,
+        int * produced_each
+    );
+
 /* Waits for the work enqueued on `hip_stream` and reports any error the
  * kernels flagged since the batch was created (their index-range checks). */
 extern DrbAmd_Status drb_amd_batch_synchronize (DrbAmd_Batch * batch, void * hip_stream);
@@ -300,6 +316,11 @@ typedef struct DrbAmd_Plan_Info
     int fast_path;          /* 1: fast arithmetic runs the matrix-core kernel,
                                0: it runs the same kernel as exact arithmetic      */
     int fast_tile_frames;   /* target frames per workgroup tile of that kernel      */
+    double fast_issued_flops_per_output_sample;   /* what that kernel hands to the
+                               matrix core per target sample (zero padding of the
+                               banded products and the warm-up segment included;
+                               one blended kernel per output instead of upstream's
+                               two or four dot products)                          */
 }
 DrbAmd_Plan_Info;
 

@@ -3,6 +3,8 @@
 Exact arithmetic must reproduce the golden vectors (produced by the upstream
 scalar build) and the CPU restatement BIT FOR BIT, for any way of cutting the
 stream into steps and tiles."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -173,3 +175,35 @@ def test_rejected_and_unsupported_requests():
     assert batch.query([1000]) == [support.oracle_lib().drb_oracle_push_count(
         support.oracle_plan(44100, 48000, 2, 4, 64, PUSH, support.GOOD)[1], 1000)]
     batch.close()
+
+
+def test_host_fed_batch_matches_device_resident_batch():
+    """Sources and targets in (pinned) host memory, handed over in slices whose
+    copies overlap the conversion: same bits as the device-resident entry,
+    over two steps so that state carried between steps is covered too."""
+    streams, ch = 37, 2
+    frames = [6000, 3100]
+    config = drbamd.make_config(44100, 48000, ch, 64, 16, PUSH, support.GOOD, streams=streams)
+    x = np.stack([support.white_noise(ch, sum(frames), 100 + s) for s in range(streams)])
+    want = []
+    for s in range(0, streams, 12):
+        status, plan = support.oracle_plan(44100, 48000, ch, 64, 16, PUSH, support.GOOD)
+        want.append((s, support.oracle_push(plan, x[s])))
+    batch = drbamd.Batch(config)
+    got = [[] for _ in range(streams)]
+    offset = 0
+    for count in frames:
+        capacity = batch.query([count] * streams)[0] + 64
+        source = torch.from_numpy(np.ascontiguousarray(x[:, :, offset:offset + count])).pin_memory()
+        target = torch.zeros((streams, ch, capacity), dtype=torch.float32).pin_memory()
+        produced = (ctypes.c_int * streams)()
+        batch.process_host_dense(source.data_ptr(), ch * count, count, target.data_ptr(), ch * capacity, capacity,
+                                 count, capacity, produced=produced)
+        for s in range(streams):
+            got[s].append(target[s, :, :produced[s]].numpy().copy())
+        offset += count
+    batch.close()
+    for s, expected in want:
+        result = np.concatenate(got[s], axis=1)
+        assert result.shape[1] <= expected.shape[1]
+        assert np.array_equal(result.view(np.uint32), expected[:, :result.shape[1]].view(np.uint32))
