@@ -223,6 +223,8 @@ void drb_audio_converter_work_memory_alignment_and_size
     *size = body ? body->plan.buffer_length * 2 * (long)sizeof(float) : 0;
 }
 
+double drb_batch_callback_latency (DrbAmd_Batch const * batch, int stream);   /* drb_batch.c */
+
 static void die (char const * what)
 {
     /* process() cannot report failure (drb-audio-converter.h:194-201) */
@@ -251,6 +253,10 @@ void drb_audio_converter_process
         int const left = frame_count - offset;
         int other = 0;
 
+        /* the callback's timestamp carries upstream's latency figure for the
+         * state this sub-block starts in (drb-audio-converter.c:3576, 3639) */
+        double const stamp = timestamp + drb_batch_callback_latency(body->batch, 0);
+
         step = left < body->plan.throttling ? left : body->plan.throttling;
 
         if (drb_amd_batch_query(body->batch, &step, &other) != drb_amd_ok) die("frame count");
@@ -267,7 +273,7 @@ void drb_audio_converter_process
              * (drb-audio-converter.c:3628-3642) */
             for (int c = 0; c < channels; c++) views[c].samples = work + (long)c * other;
 
-            body->callback.process(body->callback.state, timestamp, views, other);
+            body->callback.process(body->callback.state, stamp, views, other);
 
             for (int c = 0; c < channels; c++)
             {
@@ -303,7 +309,7 @@ void drb_audio_converter_process
 
             if (drb_amd_batch_synchronize(body->batch, 0) != drb_amd_ok) die("synchronize");
 
-            body->callback.process(body->callback.state, timestamp, views, produced);
+            body->callback.process(body->callback.state, stamp, views, produced);
         }
     }
 }

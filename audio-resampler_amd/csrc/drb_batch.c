@@ -463,6 +463,13 @@ DrbAmd_Status drb_amd_batch_reset (DrbAmd_Batch * batch, int first, int count)
 
 /* ---- stepping ---------------------------------------------------------------- */
 
+/* for the drop-in wrapper (not in the public header): the timestamp offset
+ * upstream would hand to the callback for a sub-block starting now */
+double drb_batch_callback_latency (DrbAmd_Batch const * batch, int stream)
+{
+    return drb_plan_callback_latency(&batch->plan, &batch->states[stream]);
+}
+
 DrbAmd_Status drb_amd_batch_query (DrbAmd_Batch const * batch, int const * frames, int * counts)
 {
     if (!batch || !frames || !counts) return fail(drb_amd_error_bad_argument, "null argument");

@@ -583,6 +583,47 @@ void drb_plan_geometry (Drb_Plan const * plan, int lds_budget_bytes, Drb_Geometr
     }
 }
 
+double drb_plan_callback_latency (Drb_Plan const * plan, Drb_Stream_State const * state)
+{
+    double latency = 0.0;
+
+    for (int i = 0; i < plan->pass_count; i++)
+    {
+        Drb_Pass const * const pass = &plan->passes[i];
+        int const near = plan->edges[i].rate, far = plan->edges[i + 1].rate;
+
+        switch (pass->kind)
+        {
+          case drb_pass_up2x:
+          case drb_pass_down2x:
+            latency += (double)(pass->arg / 2) / (double)(near > far ? near : far);
+            break;
+
+          case drb_pass_slicer:
+          {
+            int const a = plan->edges[i].block, b = plan->edges[i + 1].block;
+            latency += ((a > b ? a : b) / 2.0) / (double)near;
+            break;
+          }
+
+          case drb_pass_sinc:
+          {
+            double const scale = 1.0 / (double)plan->source_delta;
+            double const own = (double)(pass->arg % 100) / 2.0 + 1.0;
+
+            latency = plan->direction == 1 ? (double)state->phase * scale - own
+                                           : (double)(state->phase - 1) * scale - own;
+            break;
+          }
+
+          default:
+            break;
+        }
+    }
+
+    return latency;
+}
+
 /* ---- matrix-core geometry -------------------------------------------------- */
 
 static long long gcd_ll (long long a, long long b)

@@ -104,6 +104,17 @@ int drb_stream_step
         Drb_Plan const * plan, Drb_Stream_State * state, int frames, Drb_Step * step
     );
 
+/* What upstream adds to the timestamp it hands to the data callback for a
+ * sub-block that starts in `state` (drb-audio-converter.c:3513-3530, 3576,
+ * 3603-3620, 3639): every pass's frame-count function adds its latency in
+ * planning order -- half-bands order / 2 frames at their higher rate in seconds
+ * (1948, 1962, 2214-2224, 2303-2313), the slicer half a block in seconds (2497,
+ * 2684) -- except that the sinc stage OVERWRITES the sum with its position in
+ * source frames minus taps / 2 + 1 (1521, 1540, 1751-1766).  The mix of
+ * seconds and frames is upstream's (its author's TODO at 2497); it is
+ * replicated, not repaired, so that callbacks see the same numbers. */
+double drb_plan_callback_latency (Drb_Plan const * plan, Drb_Stream_State const * state);
+
 /* ---- kernel geometry ----------------------------------------------------- */
 
 typedef struct Drb_Geometry

@@ -150,7 +150,7 @@ class ApiHarness:
         size = self.lib.harness_sizes(src, dst, ch, bs, mbc, direction, quality, ctypes.byref(work))
         return size, work.value
 
-    def push(self, src, dst, ch, bs, mbc, quality, x, chunks, out_capacity=None):
+    def push(self, src, dst, ch, bs, mbc, quality, x, chunks, out_capacity=None, timestamp=0.0):
         x = np.ascontiguousarray(x, np.float32)
         assert x.shape[0] == ch
         n = x.shape[1]
@@ -164,13 +164,14 @@ class ApiHarness:
         produced = self.lib.harness_push(src, dst, ch, bs, mbc, quality, _fp(x), n, _ip(chunks),
                                          len(chunks), _fp(out), cap, _ip(counts), len(counts),
                                          ctypes.byref(total),
-                                         stamps.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 0.0)
+                                         stamps.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), timestamp)
         if produced < 0:
             return None
         assert total.value <= len(counts)
+        self.stamps = stamps[:total.value].copy()   # what the callbacks were told the time was
         return out[:, :produced].copy(), counts[:total.value].copy()
 
-    def pull(self, src, dst, ch, bs, mbc, quality, x, chunks):
+    def pull(self, src, dst, ch, bs, mbc, quality, x, chunks, timestamp=0.0):
         x = np.ascontiguousarray(x, np.float32)
         assert x.shape[0] == ch
         n = x.shape[1]
@@ -183,9 +184,10 @@ class ApiHarness:
         consumed = self.lib.harness_pull(src, dst, ch, bs, mbc, quality, _fp(x), n, _ip(chunks),
                                          len(chunks), _fp(out), out.shape[1], _ip(counts),
                                          len(counts), ctypes.byref(total),
-                                         stamps.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 0.0)
+                                         stamps.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), timestamp)
         if consumed < 0:
             return None
+        self.stamps = stamps[:total.value].copy()
         return out[:, :cap].copy(), counts[:total.value].copy(), consumed
 
 
