@@ -215,8 +215,6 @@ struct Tile
 {
     int index;
     int base_y;      // target index of (segment 0, row 0)
-    int base_s;      // sinc-output index of (segment 0, row 0)
-    int base_u;      // sinc-input index of (segment 0, row 0)
     int base_x;      // source index of (segment 0, row 0)
     float drift;     // sub-sample position now minus at the last exact build
     bool rebuild;    // sinc coefficients are rebuilt from the exact phase for this tile
@@ -796,6 +794,15 @@ __device__ __forceinline__ float raw_sample (int raw, int type)
          : __int_as_float(raw);
 }
 
+// Whether every frame a tile's fetch touches (FETCH groups per thread, whether
+// or not the tile has that many rows) lies inside the step's chunk.
+template <int FETCH>
+__device__ __forceinline__ bool tile_in_chunk (Drb_Fast_Chain const & chain, Drb_Device_Call const & call, int base_x)
+{
+    return base_x - chain.look_x >= 0
+        && base_x + 15 * chain.seg_x + 16 * chain.waves * FETCH - chain.look_x <= call.source_frames;
+}
+
 // Four neighbouring lanes fetch 16 consecutive frames of one segment (thread t:
 // segment (t >> 2) & 15, rows 4 (t & 3) + 16 (t >> 6) + (threads / 4) i + {0..3}), a
 // dwordx4 per group from the step's chunk or from the stream's history,
@@ -815,6 +822,21 @@ __device__ __forceinline__ void fetch_tile
     DRB_GLOBAL float const * const source = global_pointer<float const>(call.source) + channel * source_channel_stride;
     DRB_GLOBAL float const * const past =
         global_pointer<float const>(reinterpret_cast<unsigned long long>(history)) + channel * chain.history + chain.history;
+
+    // Tiles wholly inside the step's chunk (all but a stream's first and last):
+    // one address, the rest are constants of the instructions.
+    if (PLAIN && tile_in_chunk<FETCH>(chain, call, base_x))
+    {
+        DRB_GLOBAL float const * const from = source + first;
+
+        #pragma unroll
+        for (int i = 0; i < FETCH; i++)
+        {
+            fetch.v[i] = *reinterpret_cast<DRB_GLOBAL float4_unaligned const *>(from + pass * i);
+        }
+
+        return;
+    }
 
     #pragma unroll
     for (int i = 0; i < FETCH; i++)
@@ -863,6 +885,7 @@ __device__ __forceinline__ void store_tile
     int const rows = chain.seg_x + chain.look_x;
     int const first = base_x + segment * chain.seg_x + 4 * group - chain.look_x;
     int const pass = 16 * chain.waves;
+    bool const inside = PLAIN && tile_in_chunk<FETCH>(chain, call, base_x);   // no seams: as decided for the fetch
     float * const mine = buf.x + cell(4 * group, segment);
 
     #pragma unroll
@@ -881,8 +904,8 @@ __device__ __forceinline__ void store_tile
         if (pass * i >= rows) continue;
 
         int const frame = first + pass * i;
-        bool const in_chunk = frame >= 0 && frame + 4 <= call.source_frames;
-        bool const in_past = frame + 4 <= 0 && frame >= -chain.history;
+        bool const in_chunk = inside || (frame >= 0 && frame + 4 <= call.source_frames);
+        bool const in_past = !inside && frame + 4 <= 0 && frame >= -chain.history;
         float4_t & value = fetch.v[i];
 
         if (!PLAIN && in_chunk)
@@ -1004,7 +1027,11 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_fast_kernel
 
     int const delay_behind = chain.delay_place == 1 ? call.delay : 0;
     int const delay_front = chain.delay_place == 2 ? call.delay : 0;
-    int const tile_advance_s = (DOWN_STEPS ? 2 : 1) * chain.tile_frames;   // sinc outputs per tile
+    // how far the sub-sample position moves from one tile of the stream to the
+    // next, on top of the whole periods the tile advances by
+    float const drift_per_tile = static_cast<float>(static_cast<double>(
+          static_cast<long long>((DOWN_STEPS ? 2 : 1) * chain.tile_frames) * chain.target_delta
+        - static_cast<long long>(15 * chain.seg_u) * chain.source_delta) * chain.scale);
 
     // this wave's run of the fractional stage's row-block chains
     int const chains = chain.blocks * chain.periods;
@@ -1035,7 +1062,6 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_fast_kernel
 
         // segment 1 starts at the tile's first target frame
         tile.base_y = index * chain.tile_frames - chain.seg_y;
-        tile.base_s = (DOWN_STEPS ? 2 * tile.base_y : tile.base_y) - delay_behind;
         tile.inside = tile.base_y + 16 * chain.seg_y <= call.target_frames;
         tile.rebuild = since_build >= rebuild_every;
         tile.drift = 0.0f;
@@ -1067,18 +1093,14 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_fast_kernel
             since_build = 0;
         }
 
-        // tiles lie whole periods from the anchor on every edge, and the phase's
-        // departure from that is the drift the coefficients follow
+        // Tiles lie whole periods from the anchor on every edge, and the phase's
+        // departure from that is the drift the coefficients follow: the same
+        // step from each of the workgroup's tiles to the next.
         {
-            int const tiles = (tile.base_s - anchor.base_s) / tile_advance_s;
+            int const tiles = (since_build - rebuild_every / 2) * tile_stride;
 
-            tile.base_u = anchor.base_u + tiles * 15 * chain.seg_u;
             tile.base_x = anchor.base_x + tiles * 15 * chain.seg_x;
-
-            long long const advance = static_cast<long long>(tile.base_s - anchor.base_s) * chain.target_delta
-                                    - static_cast<long long>(tile.base_u - anchor.base_u) * chain.source_delta;
-
-            tile.drift = static_cast<float>(static_cast<double>(advance) * chain.scale);
+            tile.drift = static_cast<float>(tiles) * drift_per_tile;
         }
 
         since_build += 1;
