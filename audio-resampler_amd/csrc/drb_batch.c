@@ -209,6 +209,8 @@ DrbAmd_Status drb_amd_plan_info (DrbAmd_Batch_Config const * config, DrbAmd_Plan
     Drb_Fast_Chain fast;
 
     drb_plan_fast_geometry(&plan, fast_lds_budget, &fast);
+    fast.sample_type = config->sample_type;
+    fast.layout = config->layout;
     info->fast_path = fast.usable && drb_hip_fast_kernel_exists(&fast);
     info->fast_tile_frames = fast.tile_frames;
     info->fast_issued_flops_per_output_sample = 0.0;
@@ -352,11 +354,11 @@ DrbAmd_Status drb_amd_batch_create (DrbAmd_Batch_Config const * config, DrbAmd_B
 
     drb_plan_fast_geometry(&plan, fast_lds_budget, &batch->fast);
 
-    if (batch->fast.usable && !drb_hip_fast_kernel_exists(&batch->fast)) batch->fast.usable = 0;
-
     batch->fast.sample_type = config->sample_type;
     batch->fast.layout = config->layout;
     batch->fast.history = batch->geometry.history_frames;
+
+    if (batch->fast.usable && !drb_hip_fast_kernel_exists(&batch->fast)) batch->fast.usable = 0;
 
     /* timing diagnostics only: skip phases of the fast kernel (results are wrong) */
     char const * const ablate = getenv("DRB_AMD_FAST_ABLATE");

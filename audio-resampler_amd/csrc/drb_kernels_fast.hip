@@ -696,7 +696,7 @@ __device__ __forceinline__ void write_down
     (
         Drb_Fast_Chain const & chain, Drb_Device_Call const & call, Tile const & tile, Buffers const & buf,
         Lane const & lane, DRB_GLOBAL float * target_lane, int channel, long long target_channel_stride,
-        int block, float4_t acc
+        int block, float4_t acc, int first_column = 1
     )
 {
     float const * const centre = buf.d_even + 16 * (16 * block - chain.down_taps / 2 + chain.look_d) + lane.result;
@@ -705,7 +705,7 @@ __device__ __forceinline__ void write_down
     #pragma unroll
     for (int r = 0; r < 4; r++) value[r] = fmaf(0.5f, centre[16 * r], acc[r]);
 
-    if (lane.column < 1) return;
+    if (lane.column < first_column) return;
 
     if (PLAIN && tile.inside && 16 * block + 16 <= chain.seg_y)
     {
@@ -742,7 +742,7 @@ __device__ __forceinline__ void stage_down
     (
         Drb_Fast_Chain const & chain, Drb_Device_Call const & call, Tile const & tile, Buffers const & buf,
         Lane const & lane, DRB_GLOBAL float * target_lane, int channel, long long target_channel_stride,
-        int wave, float const (& a) [STEPS]
+        int wave, float const (& a) [STEPS], int first_column = 1
     )
 {
     int const blocks = (chain.seg_y + 15) / 16;
@@ -760,7 +760,7 @@ __device__ __forceinline__ void stage_down
 
         load_rows<STEPS, 64>(origin + 256 * block, b);
         write_down<PLAIN>(chain, call, tile, buf, lane, target_lane, channel, target_channel_stride, block,
-                          multiply<STEPS>(a, b));
+                          multiply<STEPS>(a, b), first_column);
     }
 }
 
@@ -1281,6 +1281,197 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_fast_kernel
 #endif
 }
 
+
+// ---- a half-band decimator on its own ----------------------------------------------------
+// Conversions that are one 2x down-sampler and nothing else (96 -> 48 kHz ...)
+// run the same banded product without the fractional stage: a tile is 16
+// segments of seg_y target frames; the source goes to LDS as its even and its
+// odd samples ([pair][16 segments] each), lookback included, so every segment
+// is output -- none is spent on warming up.  Planar float32 only.
+//   y[f] = 0.5 x[2 f - N] + sum_j h[j] x[2 (f - N + j) + 1]   (drb-audio-converter.c:2033-2057)
+
+constexpr int kPairFetch = 8;   // float4 (two sample pairs) per thread per tile: up to 256 pairs per segment of four waves
+
+struct Pair_Fetch
+{
+    float4_t v [kPairFetch];
+};
+
+// Thread t fetches pairs 2 j, 2 j + 1 of segment (t >> 2) & 15 for j = (t & 3) + 4 (t >> 6) + (threads / 16) i.
+__device__ __forceinline__ void fetch_pairs
+    (
+        Drb_Fast_Chain const & chain, Drb_Device_Call const & call, int first_frame,
+        float const * history, long long source_channel_stride, int channel, Pair_Fetch & fetch
+    )
+{
+    int const segment = (threadIdx.x >> 2) & 15, group = (threadIdx.x & 3) + 4 * (threadIdx.x >> 6);
+    int const first = first_frame + 2 * segment * chain.seg_y + 4 * group;
+    int const pass = 16 * chain.waves;   // frames between a thread's groups
+    DRB_GLOBAL float const * const source = global_pointer<float const>(call.source) + channel * source_channel_stride;
+    DRB_GLOBAL float const * const past =
+        global_pointer<float const>(reinterpret_cast<unsigned long long>(history)) + channel * chain.history + chain.history;
+
+    #pragma unroll
+    for (int i = 0; i < kPairFetch; i++)
+    {
+        int const frame = first + pass * i;
+        bool const in_chunk = frame >= 0 && frame + 4 <= call.source_frames;
+        bool const in_past = frame + 4 <= 0 && frame >= -chain.history;
+        DRB_GLOBAL float const * const from = in_chunk ? source + frame : past + (in_past ? frame : -4);
+
+        fetch.v[i] = *reinterpret_cast<DRB_GLOBAL float4_unaligned const *>(from);
+    }
+}
+
+__device__ __forceinline__ void store_pairs
+    (
+        Drb_Fast_Chain const & chain, Drb_Device_Call const & call, Buffers const & buf, int first_frame,
+        float const * history, long long source_channel_stride, int channel, Pair_Fetch & fetch
+    )
+{
+    int const segment = (threadIdx.x >> 2) & 15, group = (threadIdx.x & 3) + 4 * (threadIdx.x >> 6);
+    int const pairs = chain.seg_y + chain.look_d;
+    int const first = first_frame + 2 * segment * chain.seg_y + 4 * group;
+    int const pass = 16 * chain.waves;
+    int const mine = cell(2 * group, segment);
+
+    #pragma unroll
+    for (int i = 0; i < kPairFetch; i++)
+    {
+        asm volatile ("" : "+v"(fetch.v[i]));   // every group counts as used, whichever rows take it
+
+        int const pair = 2 * group + 8 * chain.waves * i;
+
+        if (pair >= pairs) continue;
+
+        int const frame = first + pass * i;
+        bool const in_chunk = frame >= 0 && frame + 4 <= call.source_frames;
+        bool const in_past = frame + 4 <= 0 && frame >= -chain.history;
+        float4_t & value = fetch.v[i];
+
+        // groups of four frames across a seam or an end: one by one
+        if (!in_chunk && !in_past)
+        {
+            #pragma unroll
+            for (int e = 0; e < 4; e++)
+            {
+                value[e] = source_frame<true>(chain, call, history, source_channel_stride, channel, frame + e);
+            }
+
+            asm volatile ("" : "+v"(value));
+        }
+
+        int const at = mine + 16 * 8 * chain.waves * i;
+
+        buf.d_even[at] = value[0];
+        buf.d_odd[at] = value[1];
+
+        if (pair + 1 < pairs)
+        {
+            buf.d_even[at + 16] = value[2];
+            buf.d_odd[at + 16] = value[3];
+        }
+    }
+}
+
+template <int STEPS>
+__global__ __launch_bounds__(kMaxThreads, 3) void drb_decimate_kernel
+    (
+        Drb_Fast_Chain const chain,
+        Drb_Device_Call const * __restrict__ calls, int stream_count, int tile_stride,
+        float const * __restrict__ history,
+        long long source_channel_stride, long long target_channel_stride,
+        int * fault_flag
+    )
+{
+    extern __shared__ __attribute__((aligned(16))) float lds [];
+
+    (void)fault_flag;
+
+    int const pair = blockIdx.x % (stream_count * chain.channels);
+    int const first_tile = blockIdx.x / (stream_count * chain.channels);
+    int const stream = pair / chain.channels, channel = pair - stream * chain.channels;
+    Drb_Device_Call const call = calls[stream];
+
+    if (first_tile * chain.tile_frames >= call.target_frames) return;
+
+    int const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    Lane lane;
+
+    lane.column = threadIdx.x & 15;
+    lane.quad = (threadIdx.x & 63) >> 4;
+    lane.operand = cell(lane.quad, lane.column);
+    lane.result = cell(4 * lane.quad, lane.column);
+    lane.planes = cell(2 * lane.quad, lane.column);
+    lane.sinc_even = lane.sinc_odd = 0;
+
+    Buffers const buf = { nullptr, nullptr, lds + chain.off_d_odd, lds + chain.off_d_even, nullptr };
+    float const * const stream_history = history + static_cast<long long>(stream) * chain.channels * chain.history;
+
+    // taps between 16 zeros on either side: row m of a block multiplies input k by h[k - m]
+    float * const taps_down = lds + chain.off_taps;
+
+    for (int i = threadIdx.x; i < chain.down_taps + 32; i += blockDim.x)
+    {
+        int const j = i - 15;
+        taps_down[i] = j >= 0 && j < chain.down_taps ? table_at(chain.down_table)[j] : 0.0f;
+    }
+
+    float const * const a_lane = taps_down + 15 + lane.quad - lane.column;
+
+    // the slicer's delay: in front of the filter it shifts the source, behind it the target
+    int const delay_front = chain.delay_place == 2 ? call.delay : 0;
+    int const delay_behind = chain.delay_place == 1 ? call.delay : 0;
+
+    // source frame of (segment 0, pair 0) of tile `index`
+    auto first_frame_of = [&] (int index) -> int
+    {
+        return 2 * (index * chain.tile_frames - delay_behind - chain.look_d) - delay_front;
+    };
+
+    Pair_Fetch fetch;
+
+    fetch_pairs(chain, call, first_frame_of(first_tile), stream_history, source_channel_stride, channel, fetch);
+
+    for (int index = first_tile; ; index += tile_stride)
+    {
+        Tile tile;
+
+        tile.index = index;
+        tile.base_y = index * chain.tile_frames;
+        tile.base_x = 0;
+        tile.drift = 0.0f;
+        tile.rebuild = false;
+        tile.inside = tile.base_y + 16 * chain.seg_y <= call.target_frames;
+
+        DRB_GLOBAL float * const target_lane = global_pointer<float>(call.target) + channel * target_channel_stride
+            + tile.base_y + lane.column * chain.seg_y + 4 * lane.quad;
+
+        store_pairs(chain, call, buf, first_frame_of(index), stream_history, source_channel_stride, channel, fetch);
+
+        __syncthreads();   // both planes (and the taps) in place
+
+        // the next tile's source travels while this one is filtered (the last
+        // tile fetches its own again, so that every load meets its wait)
+        bool const more = (index + tile_stride) * chain.tile_frames < call.target_frames;
+
+        fetch_pairs(chain, call, first_frame_of(more ? index + tile_stride : index), stream_history,
+                    source_channel_stride, channel, fetch);
+
+        {
+            float a [STEPS];
+
+            load_rows<STEPS, 4>(a_lane, a);
+            stage_down<STEPS, true>(chain, call, tile, buf, lane, target_lane, channel, target_channel_stride, wave, a, 0);
+        }
+
+        if (!more) break;
+
+        __syncthreads();   // the planes may be written again
+    }
+}
+
 typedef void Fast_Kernel
     (
         Drb_Fast_Chain, Drb_Device_Call const *, int, int, float const *, long long, long long, int *
@@ -1291,6 +1482,25 @@ typedef void Fast_Kernel
 // chain.ksteps for the fractional stage.
 Fast_Kernel * pick_kernel (Drb_Fast_Chain const * chain)
 {
+    if (chain->kind == 1)
+    {
+        // one half-band decimator: planar float32, up to 256 pairs per segment
+        if (chain->sample_type != kSampleF32 || chain->layout != kPlanar) return nullptr;
+        if (chain->waves != 4 || chain->seg_y + chain->look_d > 8 * chain->waves * kPairFetch) return nullptr;
+
+        switch ((chain->down_taps + 16) / 4)
+        {
+          case 6: return drb_decimate_kernel<6>;
+          case 8: return drb_decimate_kernel<8>;
+          case 10: return drb_decimate_kernel<10>;
+          case 12: return drb_decimate_kernel<12>;
+          case 14: return drb_decimate_kernel<14>;
+          case 16: return drb_decimate_kernel<16>;
+        }
+
+        return nullptr;
+    }
+
     int const up = chain->has_up ? (chain->up_taps + 16) / 4 : 0;
     int const down = chain->has_down ? (chain->down_taps + 16) / 4 : 0;
     int const key = up * 10000 + chain->ksteps * 100 + down;

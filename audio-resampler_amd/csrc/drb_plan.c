@@ -657,13 +657,40 @@ int drb_plan_fast_geometry (Drb_Plan const * plan, int lds_budget_bytes, Drb_Fas
         switch (plan->stages[k].kind)
         {
           case drb_stage_up2x: if (up >= 0 || sinc >= 0) return 0; up = k; break;
-          case drb_stage_down2x: if (down >= 0 || sinc < 0) return 0; down = k; break;
+          case drb_stage_down2x: if (down >= 0) return 0; down = k; break;
           case drb_stage_sinc: sinc = k; break;
           case drb_stage_delay: delay = k; break;
         }
     }
 
-    if (sinc < 0) return 0;
+    if (sinc >= 0 && down >= 0 && down < sinc) return 0;
+
+    if (sinc < 0)
+    {
+        /* one half-band decimator on its own (a slicer may stand on either side) */
+        if (up >= 0 || down < 0) return 0;
+        if (delay >= 0 && delay != down - 1 && delay != down + 1) return 0;
+        if (plan->stage_count != (delay >= 0 ? 2 : 1)) return 0;
+
+        chain->kind = 1;
+        chain->channels = plan->channels;
+        chain->has_down = 1;
+        chain->down_taps = plan->stages[down].arg / 2;
+        chain->down_table = half_band_table(plan->stages[down].arg);
+        chain->delay_place = delay < 0 ? 0 : delay < down ? 2 : 1;
+        chain->seg_y = 192;   /* 12 row blocks: three per wave */
+        chain->seg_s = 2 * chain->seg_y;
+        chain->look_d = chain->down_taps;
+        chain->waves = 4;
+        chain->off_d_odd = 0;
+        chain->off_d_even = (chain->seg_y + chain->look_d) * 16;
+        chain->off_taps = 2 * chain->off_d_even;
+        chain->lds_floats = chain->off_taps + chain->down_taps + 32 + 32;
+        chain->tile_frames = 16 * chain->seg_y;
+        chain->usable = chain->lds_floats * 4 <= lds_budget_bytes;
+
+        return 0;
+    }
     if (delay >= 0 && delay != sinc + 1 && delay != sinc - 1) return 0;
 
     Drb_Stage const * const stage = &plan->stages[sinc];

@@ -39,7 +39,7 @@ def assert_close(got, want, what):
 
 
 FAST_NAMES = ["cfg1_push_good", "cfg1_pull_good", "cfg1_push_fine", "cfg1_push_best",
-              "cfg1_pull_best", "cfg1_push_good_bs1", "cfg2_push_good", "cfg1_push_poor"]
+              "cfg1_pull_best", "cfg1_push_good_bs1", "cfg2_push_good", "cfg1_push_poor", "cfg3_push_good"]
 
 
 @pytest.mark.parametrize("name", FAST_NAMES)
