@@ -80,7 +80,7 @@ typedef struct Drb_Fast_Chain
     int off_x, off_u, off_d_odd, off_d_even; /* LDS float offsets                      */
     int off_bank;                           /* sinc bank while coefficients are rebuilt: shares the planes of d where a down-sampler exists */
     int off_taps;                           /* half-band taps, zero-padded: up, then down */
-    int kind;                               /* 0: [up] sinc [down]; 1: one half-band decimator on its own */
+    int kind;                               /* 0: [up] sinc [down]; 1: one half-band decimator on its own; 2: one interpolator */
     int waves;                              /* waves per workgroup: 4 or 5, whichever deals the row blocks out more evenly */
     float column_drift;                     /* sub-sample position of segment c minus segment c - 1 (0: too small to matter) */
     int types_per_wave;                     /* row-block types one wave keeps coefficients for */

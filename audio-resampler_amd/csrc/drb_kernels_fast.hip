@@ -1472,6 +1472,139 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_decimate_kernel
     }
 }
 
+
+// ---- a half-band interpolator on its own --------------------------------------------------
+// One 2x up-sampler and nothing else (48 -> 96 kHz ..., or a stage of a longer
+// chain run as a launch of its own): the source goes to LDS as for the cascade,
+// every segment is output, and a lane that holds the odd outputs of four
+// source rows reads the even ones beside them from the source plane and
+// stores eight consecutive target frames.  Planar float32 only.
+//   y[2 f] = x[f - N / 2],  y[2 f + 1] = 2 sum_j h[j] x[f - N + 1 + j]   (drb-audio-converter.c:1984-2004)
+template <int STEPS, int FETCH>
+__global__ __launch_bounds__(kMaxThreads, 3) void drb_interpolate_kernel
+    (
+        Drb_Fast_Chain const chain,
+        Drb_Device_Call const * __restrict__ calls, int stream_count, int tile_stride,
+        float const * __restrict__ history,
+        long long source_channel_stride, long long target_channel_stride,
+        int * fault_flag
+    )
+{
+    extern __shared__ __attribute__((aligned(16))) float lds [];
+
+    (void)fault_flag;
+
+    int const pair = blockIdx.x % (stream_count * chain.channels);
+    int const first_tile = blockIdx.x / (stream_count * chain.channels);
+    int const stream = pair / chain.channels, channel = pair - stream * chain.channels;
+    Drb_Device_Call const call = calls[stream];
+
+    // the slicer's delay: in front of the filter it shifts the source, behind it
+    // the target; tiles are laid out on the undelayed target, from an even frame
+    int const delay_front = chain.delay_place == 2 ? call.delay : 0;
+    int const delay_behind = chain.delay_place == 1 ? call.delay : 0;
+    int const lead = (delay_behind + 1) & ~1;
+    int const frames = call.target_frames + lead - delay_behind;   // undelayed frames to cover, from -lead
+
+    if (first_tile * chain.tile_frames >= frames) return;
+
+    int const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    Lane lane;
+
+    lane.column = threadIdx.x & 15;
+    lane.quad = (threadIdx.x & 63) >> 4;
+    lane.operand = cell(lane.quad, lane.column);
+    lane.result = cell(4 * lane.quad, lane.column);
+    lane.planes = cell(2 * lane.quad, lane.column);
+    lane.sinc_even = lane.sinc_odd = 0;
+
+    Buffers const buf = { lds + chain.off_x, nullptr, nullptr, nullptr, nullptr };
+    float const * const stream_history = history + static_cast<long long>(stream) * chain.channels * chain.history;
+
+    // taps between 16 zeros on either side: row m of a block multiplies input k by 2 h[k - m - 1]
+    float * const taps_up = lds + chain.off_taps;
+
+    for (int i = threadIdx.x; i < chain.up_taps + 32; i += blockDim.x)
+    {
+        int const j = i - 16;
+        taps_up[i] = j >= 0 && j < chain.up_taps ? 2.0f * table_at(chain.up_table)[j] : 0.0f;
+    }
+
+    float const * const a_lane = taps_up + 15 + lane.quad - lane.column;
+
+    // source frame of (segment 0, row 0) of tile `index`
+    auto base_of = [&] (int index) -> int
+    {
+        return (index * chain.tile_frames - lead) / 2 - delay_front;
+    };
+
+    Fetch<FETCH, true> fetch;
+
+    fetch_tile(chain, call, base_of(first_tile), stream_history, source_channel_stride, channel, fetch);
+
+    int const blocks = (chain.seg_x + 15) / 16;
+    float const * const origin = buf.x + 16 * (chain.look_x - chain.up_taps) + lane.operand;
+    float const * const centre = buf.x + 16 * (chain.look_x - chain.up_taps / 2) + lane.result;
+
+    for (int index = first_tile; ; index += tile_stride)
+    {
+        store_tile(chain, call, buf, base_of(index), stream_history, source_channel_stride, channel, fetch);
+
+        __syncthreads();   // source plane (and the taps) in place
+
+        bool const more = (index + tile_stride) * chain.tile_frames < frames;
+
+        fetch_tile(chain, call, base_of(more ? index + tile_stride : index), stream_history,
+                   source_channel_stride, channel, fetch);
+
+        float a [STEPS];
+
+        load_rows<STEPS, 4>(a_lane, a);
+
+        // target frame (delay included) of (segment 0, row 0)
+        int const base_y = index * chain.tile_frames - lead + delay_behind;
+        DRB_GLOBAL float * const out = global_pointer<float>(call.target) + channel * target_channel_stride;
+
+        for (int block = wave; block < blocks; block += chain.waves)
+        {
+            float b [STEPS];
+
+            load_rows<STEPS, 64>(origin + 256 * block, b);
+
+            float4_t const odd = multiply<STEPS>(a, b);
+            int const row = 16 * block + 4 * lane.quad;
+            int const frame = base_y + 2 * (lane.column * chain.seg_x + row);
+            float value [8];
+
+            #pragma unroll
+            for (int r = 0; r < 4; r++)
+            {
+                value[2 * r] = centre[16 * (16 * block + r)];
+                value[2 * r + 1] = odd[r];
+            }
+
+            if (row + 4 <= chain.seg_x && frame >= 0 && frame + 8 <= call.target_frames)
+            {
+                *reinterpret_cast<DRB_GLOBAL float4_unaligned *>(out + frame) = float4_unaligned{ value[0], value[1], value[2], value[3] };
+                *reinterpret_cast<DRB_GLOBAL float4_unaligned *>(out + frame + 4) = float4_unaligned{ value[4], value[5], value[6], value[7] };
+            }
+            else
+            {
+                #pragma unroll
+                for (int e = 0; e < 8; e++)
+                {
+                    if (row + e / 2 < chain.seg_x && frame + e >= 0 && frame + e < call.target_frames) out[frame + e] = value[e];
+                }
+            }
+        }
+
+        if (!more) break;
+
+        __syncthreads();   // the plane may be written again
+    }
+}
+
 typedef void Fast_Kernel
     (
         Drb_Fast_Chain, Drb_Device_Call const *, int, int, float const *, long long, long long, int *
@@ -1496,6 +1629,25 @@ Fast_Kernel * pick_kernel (Drb_Fast_Chain const * chain)
           case 12: return drb_decimate_kernel<12>;
           case 14: return drb_decimate_kernel<14>;
           case 16: return drb_decimate_kernel<16>;
+        }
+
+        return nullptr;
+    }
+
+    if (chain->kind == 2)
+    {
+        // one half-band interpolator: planar float32, up to 192 rows per segment
+        if (chain->sample_type != kSampleF32 || chain->layout != kPlanar) return nullptr;
+        if (chain->waves != 4 || chain->seg_x + chain->look_x > 192) return nullptr;
+
+        switch ((chain->up_taps + 16) / 4)
+        {
+          case 6: return drb_interpolate_kernel<6, 3>;
+          case 8: return drb_interpolate_kernel<8, 3>;
+          case 10: return drb_interpolate_kernel<10, 3>;
+          case 12: return drb_interpolate_kernel<12, 3>;
+          case 14: return drb_interpolate_kernel<14, 3>;
+          case 16: return drb_interpolate_kernel<16, 3>;
         }
 
         return nullptr;

@@ -665,6 +665,32 @@ int drb_plan_fast_geometry (Drb_Plan const * plan, int lds_budget_bytes, Drb_Fas
 
     if (sinc >= 0 && down >= 0 && down < sinc) return 0;
 
+    if (sinc < 0 && up >= 0)
+    {
+        /* one half-band interpolator on its own (a slicer may stand on either side) */
+        if (down >= 0) return 0;
+        if (delay >= 0 && delay != up - 1 && delay != up + 1) return 0;
+        if (plan->stage_count != (delay >= 0 ? 2 : 1)) return 0;
+
+        chain->kind = 2;
+        chain->channels = plan->channels;
+        chain->has_up = 1;
+        chain->up_taps = plan->stages[up].arg / 2;
+        chain->up_table = half_band_table(plan->stages[up].arg);
+        chain->delay_place = delay < 0 ? 0 : delay < up ? 2 : 1;
+        chain->seg_x = 128;   /* 8 row blocks: two per wave */
+        chain->seg_y = 2 * chain->seg_x;
+        chain->look_x = chain->up_taps;
+        chain->waves = 4;
+        chain->off_x = 0;
+        chain->off_taps = (chain->seg_x + chain->look_x) * 16;
+        chain->lds_floats = chain->off_taps + chain->up_taps + 32 + 32;
+        chain->tile_frames = 16 * chain->seg_y;
+        chain->usable = chain->lds_floats * 4 <= lds_budget_bytes;
+
+        return 0;
+    }
+
     if (sinc < 0)
     {
         /* one half-band decimator on its own (a slicer may stand on either side) */

@@ -39,7 +39,8 @@ def assert_close(got, want, what):
 
 
 FAST_NAMES = ["cfg1_push_good", "cfg1_pull_good", "cfg1_push_fine", "cfg1_push_best",
-              "cfg1_pull_best", "cfg1_push_good_bs1", "cfg2_push_good", "cfg1_push_poor", "cfg3_push_good"]
+              "cfg1_pull_best", "cfg1_push_good_bs1", "cfg2_push_good", "cfg1_push_poor", "cfg3_push_good",
+              "down2_pull_bs1", "up2_push_bs1", "up2_push_slicer"]
 
 
 @pytest.mark.parametrize("name", FAST_NAMES)
