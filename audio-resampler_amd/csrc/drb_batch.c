@@ -21,13 +21,34 @@
 
 enum { ring_slots = 4, max_step_frames = 1 << 24, fault_words = 128, host_slots = 3 };
 
+enum { max_launches = drb_max_stages };
+
+typedef struct Fast_Launch
+{
+    Drb_Fast_Chain fast;              /* geometry of this launch                                  */
+    Drb_Device_Chain chain;           /* for the history kernel of launches behind the first      */
+    int ups_before, downs_behind;     /* 2x stages of the plan in front of / behind this launch   */
+    int halves;                       /* 1: a decimator on its own (target = source / 2)          */
+    int doubles;                      /* 1: an interpolator on its own                            */
+    int has_sinc;
+    double rate_ratio;                /* this launch's target rate over the chain's               */
+    float * history [2];              /* device, launches behind the first                        */
+    float * output;                   /* device, planar float32 [stream][channel][output_frames]  */
+    long long output_frames;
+}
+Fast_Launch;
+
 struct DrbAmd_Batch
 {
     DrbAmd_Batch_Config config;
     Drb_Plan plan;
     Drb_Geometry geometry;
     Drb_Device_Chain chain;
-    Drb_Fast_Chain fast;              /* matrix-core path, when the plan has its shape */
+    /* matrix-core path: one launch for [up] sinc [down] and for a single 2x
+     * stage, or one per group of stages for longer chains, with planar float32
+     * buffers of the batch's own between them */
+    Fast_Launch launches [max_launches];
+    int launch_count;                 /* 0: fast arithmetic runs the cascade kernel */
     int device;
     int sample_bytes;
 
@@ -172,6 +193,134 @@ static DrbAmd_Status resolve (DrbAmd_Batch_Config const * config, Drb_Plan * pla
 
 enum { lds_budget = 56 * 1024, fast_lds_budget = 78 * 1024 };
 
+/* ---- plan -> launches of the matrix-core path -------------------------------- */
+
+/* Cuts the plan's stages into launches: every 2x up-sampler but the one next to
+ * the sinc stage runs on its own, then [up] [slicer] sinc [slicer] [down] in one
+ * launch, then every further down-sampler on its own; chains without a sinc
+ * stage are 2x stages only, one launch each (the slicer with the last
+ * up-sampler or the first down-sampler).  Returns the number of launches, 0 if
+ * some launch has no kernel (fast arithmetic then runs the cascade kernel). */
+static int build_launches (DrbAmd_Batch_Config const * config, Drb_Plan const * plan, Fast_Launch * launches)
+{
+    int sinc = -1, count = 0;
+    int first [max_launches], last [max_launches];
+
+    for (int k = 0; k < plan->stage_count; k++) if (plan->stages[k].kind == drb_stage_sinc) sinc = k;
+
+    if (sinc >= 0)
+    {
+        int lo = sinc, hi = sinc;
+
+        while (lo > 0 && plan->stages[lo - 1].kind == drb_stage_delay) lo--;
+        if (lo > 0 && plan->stages[lo - 1].kind == drb_stage_up2x) lo--;
+        while (hi + 1 < plan->stage_count && plan->stages[hi + 1].kind == drb_stage_delay) hi++;
+        if (hi + 1 < plan->stage_count && plan->stages[hi + 1].kind == drb_stage_down2x) hi++;
+
+        for (int k = 0; k < lo; k++) { first[count] = last[count] = k; count++; }
+        first[count] = lo; last[count] = hi; count++;
+        for (int k = hi + 1; k < plan->stage_count; k++) { first[count] = last[count] = k; count++; }
+    }
+    else
+    {
+        for (int k = 0; k < plan->stage_count; k++)
+        {
+            if (plan->stages[k].kind == drb_stage_delay)
+            {
+                /* with the launch in front of it, or, at the head of the chain, behind it */
+                if (count > 0) last[count - 1] = k;
+                else { first[count] = last[count] = k; count++; }
+            }
+            else if (count > 0 && plan->stages[last[count - 1]].kind == drb_stage_delay && first[count - 1] == last[count - 1])
+            {
+                last[count - 1] = k;
+            }
+            else
+            {
+                first[count] = last[count] = k; count++;
+            }
+        }
+    }
+
+    if (count < 1 || count > max_launches) return 0;
+
+    for (int i = 0; i < count; i++)
+    {
+        Fast_Launch * const launch = &launches[i];
+        Drb_Plan part = *plan;
+        Drb_Geometry geometry;
+
+        memset(launch, 0, sizeof(*launch));
+
+        part.stage_count = last[i] - first[i] + 1;
+        memmove(part.stages, plan->stages + first[i], sizeof(Drb_Stage) * (size_t)part.stage_count);
+
+        launch->rate_ratio = (double)plan->stages[last[i]].out_rate / (double)plan->stages[plan->stage_count - 1].out_rate;
+
+        for (int k = 0; k < first[i]; k++) if (plan->stages[k].kind == drb_stage_up2x) launch->ups_before++;
+        for (int k = last[i] + 1; k < plan->stage_count; k++) if (plan->stages[k].kind == drb_stage_down2x) launch->downs_behind++;
+
+        for (int k = 0; k < part.stage_count; k++)
+        {
+            if (part.stages[k].kind == drb_stage_sinc) launch->has_sinc = 1;
+        }
+
+        if (!launch->has_sinc)
+        {
+            for (int k = 0; k < part.stage_count; k++)
+            {
+                if (part.stages[k].kind == drb_stage_up2x) launch->doubles = 1;
+                if (part.stages[k].kind == drb_stage_down2x) launch->halves = 1;
+            }
+
+            if (!launch->doubles && !launch->halves) return 0;   /* a slicer alone: re-blocking, no filter */
+        }
+
+        drb_plan_geometry(&part, lds_budget, &geometry);
+        drb_plan_fast_geometry(&part, fast_lds_budget, &launch->fast);
+
+        /* buffers between launches are planar float32 */
+        DrbAmd_Batch_Config between = *config;
+
+        between.sample_type = drb_amd_sample_f32;
+        between.layout = drb_amd_layout_planar;
+
+        build_chain(i == 0 ? config : &between, &part, &geometry, &launch->chain);
+
+        launch->fast.sample_type = i == 0 ? (int)config->sample_type : (int)drb_amd_sample_f32;
+        launch->fast.layout = i == 0 ? (int)config->layout : (int)drb_amd_layout_planar;
+        launch->fast.target_sample_type = i == count - 1 ? (int)config->sample_type : (int)drb_amd_sample_f32;
+        launch->fast.target_layout = i == count - 1 ? (int)config->layout : (int)drb_amd_layout_planar;
+        launch->fast.history = geometry.history_frames;
+
+        if (!launch->fast.usable || !drb_hip_fast_kernel_exists(&launch->fast)) return 0;
+    }
+
+    return count;
+}
+
+/* what the launches hand to the matrix core per target sample of the whole chain */
+static double issued_flops (Fast_Launch const * launches, int count)
+{
+    double total = 0.0;
+
+    for (int i = 0; i < count; i++)
+    {
+        Drb_Fast_Chain const * const fast = &launches[i].fast;
+
+        /* 16 x 16 x 4 products of 2048 flop each, per tile of one channel */
+        long const up_blocks = fast->has_up ? (fast->seg_x + 15) / 16 : 0;
+        long const down_blocks = fast->has_down ? (fast->seg_y + 15) / 16 : 0;
+        long const products = up_blocks * ((fast->up_taps + 16) / 4)
+                            + (long)fast->blocks * fast->periods * fast->ksteps * (fast->column_drift != 0.0f ? 2 : 1)
+                            + down_blocks * ((fast->down_taps + 16) / 4);
+
+        total += 2048.0 * (double)products / (double)fast->tile_frames * launches[i].rate_ratio;
+    }
+
+    return total;
+}
+
 DrbAmd_Status drb_amd_plan_info (DrbAmd_Batch_Config const * config, DrbAmd_Plan_Info * info)
 {
     Drb_Plan plan;
@@ -206,26 +355,18 @@ DrbAmd_Status drb_amd_plan_info (DrbAmd_Batch_Config const * config, DrbAmd_Plan
     info->bytes_per_output_sample =
         sample_bytes * ((double)plan.source_rate / plan.target_rate) + sample_bytes;
 
-    Drb_Fast_Chain fast;
+    Fast_Launch * const launches = calloc(max_launches, sizeof(Fast_Launch));
 
-    drb_plan_fast_geometry(&plan, fast_lds_budget, &fast);
-    fast.sample_type = config->sample_type;
-    fast.layout = config->layout;
-    info->fast_path = fast.usable && drb_hip_fast_kernel_exists(&fast);
-    info->fast_tile_frames = fast.tile_frames;
-    info->fast_issued_flops_per_output_sample = 0.0;
+    if (!launches) return fail(drb_amd_error_out_of_memory, "out of host memory");
 
-    if (info->fast_path)
-    {
-        /* 16 x 16 x 4 products of 2048 flop each, per tile of one channel */
-        long const up_blocks = fast.has_up ? (fast.seg_x + 15) / 16 : 0;
-        long const down_blocks = fast.has_down ? (fast.seg_y + 15) / 16 : 0;
-        long const products = up_blocks * ((fast.up_taps + 16) / 4)
-                            + (long)fast.blocks * fast.periods * fast.ksteps * (fast.column_drift != 0.0f ? 2 : 1)
-                            + down_blocks * ((fast.down_taps + 16) / 4);
+    int const count = build_launches(config, &plan, launches);
 
-        info->fast_issued_flops_per_output_sample = 2048.0 * (double)products / (double)fast.tile_frames;
-    }
+    info->fast_path = count > 0;
+    info->fast_launches = count;
+    info->fast_tile_frames = count > 0 ? launches[count - 1].fast.tile_frames : 0;
+    info->fast_issued_flops_per_output_sample = issued_flops(launches, count);
+
+    free(launches);
 
     return drb_amd_ok;
 }
@@ -293,6 +434,13 @@ static void release (DrbAmd_Batch * batch)
 
     for (int i = 0; i < 3; i++) if (batch->feed_streams[i]) drb_hip_stream_destroy(batch->feed_streams[i]);
 
+    for (int i = 0; i < max_launches; i++)
+    {
+        if (batch->launches[i].history[0]) drb_hip_free(batch->launches[i].history[0]);
+        if (batch->launches[i].history[1]) drb_hip_free(batch->launches[i].history[1]);
+        if (batch->launches[i].output) drb_hip_free(batch->launches[i].output);
+    }
+
     if (batch->kernel_start) drb_hip_event_destroy(batch->kernel_start);
     if (batch->kernel_stop) drb_hip_event_destroy(batch->kernel_stop);
     if (batch->history[0]) drb_hip_free(batch->history[0]);
@@ -352,17 +500,15 @@ DrbAmd_Status drb_amd_batch_create (DrbAmd_Batch_Config const * config, DrbAmd_B
     drb_plan_geometry(&plan, lds_budget, &batch->geometry);
     build_chain(config, &plan, &batch->geometry, &batch->chain);
 
-    drb_plan_fast_geometry(&plan, fast_lds_budget, &batch->fast);
+    batch->launch_count = build_launches(config, &plan, batch->launches);
 
-    batch->fast.sample_type = config->sample_type;
-    batch->fast.layout = config->layout;
-    batch->fast.history = batch->geometry.history_frames;
-
-    if (batch->fast.usable && !drb_hip_fast_kernel_exists(&batch->fast)) batch->fast.usable = 0;
+    /* the first launch reads the history the batch keeps for the whole chain */
+    if (batch->launch_count > 0) batch->launches[0].fast.history = batch->geometry.history_frames;
 
     /* timing diagnostics only: skip phases of the fast kernel (results are wrong) */
     char const * const ablate = getenv("DRB_AMD_FAST_ABLATE");
-    batch->fast.ablate = ablate ? atoi(ablate) : 0;
+
+    for (int i = 0; i < batch->launch_count; i++) batch->launches[i].fast.ablate = ablate ? atoi(ablate) : 0;
 
     size_t const n = (size_t)config->stream_count;
 
@@ -388,14 +534,22 @@ DrbAmd_Status drb_amd_batch_create (DrbAmd_Batch_Config const * config, DrbAmd_B
 
     code = drb_hip_alloc((void **)&batch->history[0], history_bytes);
     if (!code) code = drb_hip_alloc((void **)&batch->history[1], history_bytes);
-    if (!code) code = drb_hip_alloc((void **)&batch->calls_device, n * sizeof(Drb_Device_Call));
+    if (!code) code = drb_hip_alloc((void **)&batch->calls_device, n * max_launches * sizeof(Drb_Device_Call));
     if (!code) code = drb_hip_alloc((void **)&batch->fault_device, fault_words * sizeof(long long));
     if (!code) code = drb_hip_host_alloc((void **)&batch->fault_host, sizeof(int));
 
     for (int i = 0; i < ring_slots && !code; i++)
     {
-        code = drb_hip_host_alloc((void **)&batch->calls_host[i], n * sizeof(Drb_Device_Call));
+        code = drb_hip_host_alloc((void **)&batch->calls_host[i], n * max_launches * sizeof(Drb_Device_Call));
         if (!code) code = drb_hip_event_create(&batch->slot_done[i]);
+    }
+
+    for (int i = 1; i < batch->launch_count && !code; i++)
+    {
+        size_t const bytes = n * plan.channels * (size_t)batch->launches[i].chain.history * sizeof(float);
+
+        code = drb_hip_alloc((void **)&batch->launches[i].history[0], bytes);
+        if (!code) code = drb_hip_alloc((void **)&batch->launches[i].history[1], bytes);
     }
 
     if (!code) code = drb_hip_memset_async(batch->fault_device, 0, fault_words * sizeof(long long), 0);
@@ -453,6 +607,16 @@ DrbAmd_Status drb_amd_batch_reset (DrbAmd_Batch * batch, int first, int count)
     for (int i = 0; i < 2 && !code; i++)
     {
         code = drb_hip_memset_async((char *)batch->history[i] + first * per_stream, 0, count * per_stream, 0);
+    }
+
+    for (int l = 1; l < batch->launch_count && !code; l++)
+    {
+        size_t const each = (size_t)batch->plan.channels * batch->launches[l].chain.history * sizeof(float);
+
+        for (int i = 0; i < 2 && !code; i++)
+        {
+            code = drb_hip_memset_async((char *)batch->launches[l].history[i] + first * each, 0, count * each, 0);
+        }
     }
 
     if (!code) code = drb_hip_stream_synchronize(0);
@@ -545,38 +709,118 @@ DrbAmd_Status drb_amd_batch_process
     }
 
     Drb_Device_Call * const calls = batch->calls_host[slot];
+    int const fast = batch->config.arithmetic == drb_amd_arithmetic_fast && batch->launch_count > 0;
+    int const launches = fast ? batch->launch_count : 1;
+    long long most [max_launches];   /* most frames any stream gets out of each launch */
+
+    /* frames between the launches: an interpolator on its own doubles what it
+     * gets; everything from the sinc stage on is counted back from the target */
+    for (int l = 0; l < launches; l++) most[l] = 0;
+
+    for (int s = 0; s < n; s++)
+    {
+        long long frames = batch->steps[s].source_frames;
+
+        for (int l = 0; l < launches; l++)
+        {
+            Fast_Launch const * const launch = &batch->launches[l];
+
+            frames = l == launches - 1 ? batch->steps[s].target_frames
+                   : launch->doubles ? 2 * frames
+                   : (long long)batch->steps[s].target_frames << launch->downs_behind;
+
+            if (frames > most[l]) most[l] = frames;
+        }
+    }
+
+    /* the batch's buffers between launches grow when a step needs more */
+    for (int l = 0; l + 1 < launches; l++)
+    {
+        Fast_Launch * const launch = &batch->launches[l];
+
+        if (most[l] > launch->output_frames)
+        {
+            long long const frames = (most[l] + most[l] / 4 + 255) / 256 * 256;
+
+            if ((code = drb_hip_stream_synchronize(hip_stream)) != 0) return fail_hip("hipStreamSynchronize", code);
+            if (launch->output) drb_hip_free(launch->output);
+
+            launch->output = 0;
+            launch->output_frames = 0;
+
+            if ((code = drb_hip_alloc((void **)&launch->output, (size_t)n * batch->plan.channels * (size_t)frames * sizeof(float))) != 0)
+            {
+                return fail(drb_amd_error_out_of_memory, "buffer between launches: %s", drb_hip_error_text(code));
+            }
+
+            launch->output_frames = frames;
+        }
+    }
 
     for (int s = 0; s < n; s++)
     {
         Drb_Step const * const step = &batch->steps[s];
+        long long frames = step->source_frames;
 
-        calls[s].source = (unsigned long long)(size_t)source[s];
-        calls[s].target = (unsigned long long)(size_t)target[s];
-        calls[s].phase = step->phase;
-        calls[s].source_frames = step->source_frames;
-        calls[s].target_frames = step->target_frames;
-        calls[s].delay = step->delay;
-        calls[s].reserved = 0;
+        for (int l = 0; l < launches; l++)
+        {
+            Fast_Launch const * const launch = &batch->launches[l];
+            Fast_Launch const * const before = l > 0 ? &batch->launches[l - 1] : 0;
+            Drb_Device_Call * const call = &calls[(size_t)l * n + s];
+            long long const out = l == launches - 1 ? step->target_frames
+                                : launch->doubles ? 2 * frames
+                                : (long long)step->target_frames << launch->downs_behind;
+
+            call->source = before ? (unsigned long long)(size_t)(before->output + (size_t)s * batch->plan.channels * before->output_frames)
+                                  : (unsigned long long)(size_t)source[s];
+            call->target = l == launches - 1 ? (unsigned long long)(size_t)target[s]
+                         : (unsigned long long)(size_t)(launch->output + (size_t)s * batch->plan.channels * launch->output_frames);
+            call->phase = step->phase;
+            call->source_frames = (int)frames;
+            call->target_frames = (int)out;
+            call->delay = step->delay;
+            call->reserved = 0;
+
+            frames = out;
+        }
     }
 
-    float * const history_in = batch->history[batch->history_current];
-    float * const history_out = batch->history[batch->history_current ^ 1];
+    int const current = batch->history_current;
+    float * const history_in = batch->history[current];
+    float * const history_out = batch->history[current ^ 1];
     int const tile = batch->geometry.tile_frames;
 
-    code = drb_hip_upload_async(batch->calls_device, calls, (size_t)n * sizeof(Drb_Device_Call), hip_stream);
+    code = drb_hip_upload_async(batch->calls_device, calls, (size_t)n * launches * sizeof(Drb_Device_Call), hip_stream);
 
     if (!code && batch->timing) code = drb_hip_event_record(batch->kernel_start, hip_stream);
 
-    if (!code && batch->config.arithmetic == drb_amd_arithmetic_fast && batch->fast.usable)
+    if (fast)
     {
-        int const fast_tile = batch->fast.tile_frames;
+        for (int l = 0; l < launches && !code; l++)
+        {
+            Fast_Launch const * const launch = &batch->launches[l];
+            Drb_Device_Call const * const launch_calls = batch->calls_device + (size_t)l * n;
+            long long const source_stride = l == 0 ? source_channel_stride : batch->launches[l - 1].output_frames;
+            long long const target_stride = l == launches - 1 ? target_channel_stride : launch->output_frames;
+            int const fast_tile = launch->fast.tile_frames;
 
-        code = drb_hip_launch_fast
-        (
-            &batch->fast, batch->calls_device, n, (most_target + fast_tile - 1) / fast_tile,
-            history_in, source_channel_stride, target_channel_stride,
-            batch->fault_device, hip_stream
-        );
+            code = drb_hip_launch_fast
+            (
+                &launch->fast, launch_calls, n, (int)((most[l] + fast_tile - 1) / fast_tile),
+                l == 0 ? history_in : launch->history[current], source_stride, target_stride,
+                batch->fault_device, hip_stream
+            );
+
+            /* what this launch read becomes the history of its next step */
+            if (!code && l > 0)
+            {
+                code = drb_hip_launch_history
+                (
+                    &launch->chain, launch_calls, n, launch->history[current], launch->history[current ^ 1],
+                    source_stride, hip_stream
+                );
+            }
+        }
     }
     else if (!code)
     {

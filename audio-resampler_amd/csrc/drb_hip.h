@@ -64,7 +64,8 @@ typedef struct Drb_Fast_Chain
 {
     int usable;
     int ablate;                             /* diagnostic: bit mask of phases to skip (timing only) */
-    int channels, sample_type, layout, history;
+    int channels, sample_type, layout, history;   /* sample_type, layout: of the source */
+    int target_sample_type, target_layout;
     int has_up, up_taps, up_table;          /* half-band in front of the sinc stage   */
     int has_down, down_taps, down_table;    /* half-band behind it                    */
     int sinc_taps, sinc_cubic, sinc_table, sinc_pull;

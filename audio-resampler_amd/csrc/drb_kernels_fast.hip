@@ -157,11 +157,11 @@ __device__ __forceinline__ void target_frame
         return;
     }
 
-    long long const index = chain.layout == kInterleaved
+    long long const index = chain.target_layout == kInterleaved
         ? static_cast<long long>(frame) * chain.channels + channel
         : channel * channel_stride + frame;
 
-    store_sample(call.target, index, chain.sample_type, value);
+    store_sample(call.target, index, chain.target_sample_type, value);
 }
 
 // Source frames consumed before the output with accumulator value `phase`, and
@@ -1287,7 +1287,7 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_fast_kernel
 // run the same banded product without the fractional stage: a tile is 16
 // segments of seg_y target frames; the source goes to LDS as its even and its
 // odd samples ([pair][16 segments] each), lookback included, so every segment
-// is output -- none is spent on warming up.  Planar float32 only.
+// is output -- none is spent on warming up.  Planar float32 sources only.
 //   y[f] = 0.5 x[2 f - N] + sum_j h[j] x[2 (f - N + j) + 1]   (drb-audio-converter.c:2033-2057)
 
 constexpr int kPairFetch = 8;   // float4 (two sample pairs) per thread per tile: up to 256 pairs per segment of four waves
@@ -1374,7 +1374,7 @@ __device__ __forceinline__ void store_pairs
     }
 }
 
-template <int STEPS>
+template <int STEPS, bool PLAIN_OUT>
 __global__ __launch_bounds__(kMaxThreads, 3) void drb_decimate_kernel
     (
         Drb_Fast_Chain const chain,
@@ -1463,7 +1463,7 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_decimate_kernel
             float a [STEPS];
 
             load_rows<STEPS, 4>(a_lane, a);
-            stage_down<STEPS, true>(chain, call, tile, buf, lane, target_lane, channel, target_channel_stride, wave, a, 0);
+            stage_down<STEPS, PLAIN_OUT>(chain, call, tile, buf, lane, target_lane, channel, target_channel_stride, wave, a, 0);
         }
 
         if (!more) break;
@@ -1617,27 +1617,35 @@ Fast_Kernel * pick_kernel (Drb_Fast_Chain const * chain)
 {
     if (chain->kind == 1)
     {
-        // one half-band decimator: planar float32, up to 256 pairs per segment
+        // one half-band decimator: planar float32 source, up to 256 pairs per segment
         if (chain->sample_type != kSampleF32 || chain->layout != kPlanar) return nullptr;
         if (chain->waves != 4 || chain->seg_y + chain->look_d > 8 * chain->waves * kPairFetch) return nullptr;
 
+        bool const plain_out = chain->target_sample_type == kSampleF32 && chain->target_layout == kPlanar;
+
+#define DRB_DECIMATE_CASE(STEPS) \
+          case STEPS: return plain_out ? drb_decimate_kernel<STEPS, true> : drb_decimate_kernel<STEPS, false>;
+
         switch ((chain->down_taps + 16) / 4)
         {
-          case 6: return drb_decimate_kernel<6>;
-          case 8: return drb_decimate_kernel<8>;
-          case 10: return drb_decimate_kernel<10>;
-          case 12: return drb_decimate_kernel<12>;
-          case 14: return drb_decimate_kernel<14>;
-          case 16: return drb_decimate_kernel<16>;
+          DRB_DECIMATE_CASE(6)
+          DRB_DECIMATE_CASE(8)
+          DRB_DECIMATE_CASE(10)
+          DRB_DECIMATE_CASE(12)
+          DRB_DECIMATE_CASE(14)
+          DRB_DECIMATE_CASE(16)
         }
+
+#undef DRB_DECIMATE_CASE
 
         return nullptr;
     }
 
     if (chain->kind == 2)
     {
-        // one half-band interpolator: planar float32, up to 192 rows per segment
+        // one half-band interpolator: planar float32 on both sides, up to 192 rows per segment
         if (chain->sample_type != kSampleF32 || chain->layout != kPlanar) return nullptr;
+        if (chain->target_sample_type != kSampleF32 || chain->target_layout != kPlanar) return nullptr;
         if (chain->waves != 4 || chain->seg_x + chain->look_x > 192) return nullptr;
 
         switch ((chain->up_taps + 16) / 4)
@@ -1661,7 +1669,8 @@ Fast_Kernel * pick_kernel (Drb_Fast_Chain const * chain)
 
     if (chain->waves * 64 > kMaxThreads || chain->waves < 1) return nullptr;
 
-    bool const plain = chain->sample_type == kSampleF32 && chain->layout == kPlanar;
+    bool const plain = chain->sample_type == kSampleF32 && chain->layout == kPlanar
+                    && chain->target_sample_type == kSampleF32 && chain->target_layout == kPlanar;
 
 #define DRB_FAST_CASE(KEY, UP, SINC, DOWN, FETCH, CUBIC) \
       case KEY: if (rows > pass * FETCH || (chain->sinc_cubic != 0) != CUBIC) return nullptr; \
@@ -1676,6 +1685,11 @@ Fast_Kernel * pick_kernel (Drb_Fast_Chain const * chain)
       DRB_FAST_CASE(120912, 12, 9, 12, 3, true)
       DRB_FAST_CASE(161216, 16, 12, 16, 4, true)   // best
       DRB_FAST_CASE(161316, 16, 13, 16, 4, true)
+      DRB_FAST_CASE(101414, 10, 14, 14, 4, false) // 64 -> 128 -> 96 -> 48 kHz: the core of 16 -> 48 kHz, good
+      DRB_FAST_CASE(161312, 16, 13, 12, 4, true)  // 192 -> 384 -> 352.8 -> 176.4 kHz: the core of 192 -> 44.1 kHz, best
+      DRB_FAST_CASE(141310, 14, 13, 10, 4, false) // the same, good
+      DRB_FAST_CASE(81414, 8, 14, 14, 4, false)   // the core of 8 -> 48 kHz, good
+      DRB_FAST_CASE(141208, 14, 12, 8, 3, false)  // the core of 48 -> 8 kHz, good
       DRB_FAST_CASE(800, 0, 8, 0, 4, false)         // poor
       DRB_FAST_CASE(900, 0, 9, 0, 4, false)
     }

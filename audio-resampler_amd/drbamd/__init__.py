@@ -50,7 +50,7 @@ class PlanInfo(ctypes.Structure):
                 ("history_frames", ctypes.c_int), ("tile_frames", ctypes.c_int),
                 ("flops_per_output_sample", ctypes.c_double),
                 ("bytes_per_output_sample", ctypes.c_double),
-                ("fast_path", ctypes.c_int), ("fast_tile_frames", ctypes.c_int),
+                ("fast_path", ctypes.c_int), ("fast_tile_frames", ctypes.c_int), ("fast_launches", ctypes.c_int),
                 ("fast_issued_flops_per_output_sample", ctypes.c_double)]
 
     def stages(self):

@@ -316,6 +316,8 @@ typedef struct DrbAmd_Plan_Info
     int fast_path;          /* 1: fast arithmetic runs the matrix-core kernel,
                                0: it runs the same kernel as exact arithmetic      */
     int fast_tile_frames;   /* target frames per workgroup tile of that kernel      */
+    int fast_launches;      /* kernel launches of that path per step (longer chains
+                               run their outer 2x stages as launches of their own) */
     double fast_issued_flops_per_output_sample;   /* what that kernel hands to the
                                matrix core per target sample (zero padding of the
                                banded products and the warm-up segment included;
