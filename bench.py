@@ -239,7 +239,13 @@ def main():
     except OSError:
         pass
 
-    roofline.update({"traffic": traffic, "kernel": "drb_fast_kernel" if fast else "drb_cascade_kernel",
+    kernel = "drb_cascade_kernel"
+    if fast:
+        kinds = set(kind for kind in info.stage_kind[:info.stage_count] if kind != 4)
+        kernel = "drb_fast_kernel" if 3 in kinds else "drb_decimate_kernel" if kinds == {2} else "drb_interpolate_kernel"
+        if info.fast_launches > 1:
+            kernel += " + %d half-band launches" % (info.fast_launches - 1)
+    roofline.update({"traffic": traffic, "kernel": kernel,
                      "kernel_ms": round(mean_ms, 4),
                      "algorithmic_flops_per_sample": round(info.flops_per_output_sample, 1),
                      "algorithmic_bytes_per_sample": round(info.bytes_per_output_sample, 3),
