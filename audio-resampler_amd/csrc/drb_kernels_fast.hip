@@ -164,6 +164,60 @@ __device__ __forceinline__ void target_frame
     store_sample(call.target, index, chain.target_sample_type, value);
 }
 
+// Four consecutive target frames of one channel (not planar float32): where
+// they lie together in the buffer they leave as one store.
+__device__ __forceinline__ void target_four
+    (
+        Drb_Fast_Chain const & chain, Drb_Device_Call const & call,
+        long long channel_stride, int channel, int frame, float const (& value) [4]
+    )
+{
+    typedef int int4_unaligned __attribute__((ext_vector_type(4), aligned(4)));
+    typedef int int2_unaligned __attribute__((ext_vector_type(2), aligned(2)));
+
+    bool const contiguous = chain.target_layout == kPlanar || chain.channels == 1;
+    long long const index = chain.target_layout == kInterleaved
+        ? static_cast<long long>(frame) * chain.channels + channel
+        : channel * channel_stride + frame;
+
+    if (contiguous && chain.target_sample_type == kSampleI16)
+    {
+        int q [4];
+
+        #pragma unroll
+        for (int r = 0; r < 4; r++)
+        {
+            float const scaled = rintf(value[r] * 32768.0f);
+
+            q[r] = scaled >= 32767.0f ? 32767 : scaled <= -32768.0f ? -32768 : scaled != scaled ? 0 : static_cast<int>(scaled);
+        }
+
+        *reinterpret_cast<DRB_GLOBAL int2_unaligned *>(global_pointer<short>(call.target) + index) =
+            int2_unaligned{ (q[0] & 0xffff) | (q[1] << 16), (q[2] & 0xffff) | (q[3] << 16) };
+        return;
+    }
+
+    if (contiguous && chain.target_sample_type == kSampleI32)
+    {
+        int q [4];
+
+        #pragma unroll
+        for (int r = 0; r < 4; r++)
+        {
+            float const scaled = rintf(value[r] * 2147483648.0f);
+
+            q[r] = scaled >= 2147483648.0f ? 2147483647 : scaled <= -2147483648.0f ? (-2147483647 - 1)
+                 : scaled != scaled ? 0 : static_cast<int>(scaled);
+        }
+
+        *reinterpret_cast<DRB_GLOBAL int4_unaligned *>(global_pointer<int>(call.target) + index) = int4_unaligned{ q[0], q[1], q[2], q[3] };
+        return;
+    }
+
+    #pragma unroll
+    for (int r = 0; r < 4; r++) target_frame<false>(chain, call, channel_stride, channel, frame + r, value[r]);
+}
+
 // Source frames consumed before the output with accumulator value `phase`, and
 // its sub-sample position (drb-audio-converter.c:1617-1648 push, 1677-1707 pull).
 __device__ __forceinline__ void sinc_position
@@ -594,8 +648,9 @@ __device__ __forceinline__ void write_sinc
         {
             int const frame = tile.base_y + lane.column * chain.seg_y + first + 4 * lane.quad;
 
-            #pragma unroll
-            for (int r = 0; r < 4; r++) target_frame<PLAIN>(chain, call, target_channel_stride, channel, frame + r, acc[r]);
+            float const four [4] = { acc[0], acc[1], acc[2], acc[3] };
+
+            target_four(chain, call, target_channel_stride, channel, frame, four);
 
             return;
         }
@@ -718,8 +773,7 @@ __device__ __forceinline__ void write_down
     {
         int const frame = tile.base_y + lane.column * chain.seg_y + 16 * block + 4 * lane.quad;
 
-        #pragma unroll
-        for (int r = 0; r < 4; r++) target_frame<PLAIN>(chain, call, target_channel_stride, channel, frame + r, value[r]);
+        target_four(chain, call, target_channel_stride, channel, frame, value);
 
         return;
     }
@@ -769,13 +823,17 @@ __device__ __forceinline__ void stage_down
 // What a thread holds of the next tile: FETCH groups of four consecutive
 // frames, (threads / 4) rows apart -- up to (threads / 4) FETCH rows of 16
 // segments per workgroup.  Planar float32 sources travel as the floats they
-// are; other sample types and layouts as four raw samples per group plus the
-// four floats of history that may stand in their place.
+// are, other sample types and layouts as raw words, converted when stored.
 template <int FETCH, bool PLAIN>
 struct Fetch
 {
-    float4_t v [FETCH];                    // PLAIN: the frames; else: from the history
-    int raw [PLAIN ? 1 : FETCH][4];        // else: from the step's chunk, unconverted
+    float4_t v [FETCH];
+};
+
+template <int FETCH>
+struct Fetch<FETCH, false>
+{
+    int raw [FETCH][4];
 };
 
 __device__ __forceinline__ long long chunk_index
@@ -785,6 +843,20 @@ __device__ __forceinline__ long long chunk_index
 {
     return chain.layout == kInterleaved ? static_cast<long long>(frame) * chain.channels + channel
                                         : channel * channel_stride + frame;
+}
+
+// How four consecutive frames of one channel lie in the chunk:
+//   0  apart: one load per sample
+//   1  16-bit, two interleaved channels: the four frames are one dwordx4, a dword per frame
+//   2  16-bit, contiguous (planar, or one channel): one dwordx2
+//   3  32-bit, contiguous: one dwordx4
+__device__ __forceinline__ int chunk_packing (Drb_Fast_Chain const & chain)
+{
+    bool const contiguous = chain.layout == kPlanar || chain.channels == 1;
+
+    if (chain.sample_type == kSampleI16) return contiguous ? 2 : chain.channels == 2 ? 1 : 0;
+
+    return contiguous ? 3 : 0;
 }
 
 __device__ __forceinline__ float raw_sample (int raw, int type)
@@ -809,11 +881,11 @@ __device__ __forceinline__ bool tile_in_chunk (Drb_Fast_Chain const & chain, Drb
 // whichever holds all four frames.  The loads are unconditional (a group that
 // straddles a seam or an end reads the last history frames instead and is
 // mended when the tile is stored), so that nothing waits for them before then.
-template <int FETCH, bool PLAIN>
+template <int FETCH>
 __device__ __forceinline__ void fetch_tile
     (
         Drb_Fast_Chain const & chain, Drb_Device_Call const & call, int base_x,
-        float const * history, long long source_channel_stride, int channel, Fetch<FETCH, PLAIN> & fetch
+        float const * history, long long source_channel_stride, int channel, Fetch<FETCH, true> & fetch
     )
 {
     int const segment = (threadIdx.x >> 2) & 15, group = (threadIdx.x & 3) + 4 * (threadIdx.x >> 6);
@@ -825,7 +897,7 @@ __device__ __forceinline__ void fetch_tile
 
     // Tiles wholly inside the step's chunk (all but a stream's first and last):
     // one address, the rest are constants of the instructions.
-    if (PLAIN && tile_in_chunk<FETCH>(chain, call, base_x))
+    if (tile_in_chunk<FETCH>(chain, call, base_x))
     {
         DRB_GLOBAL float const * const from = source + first;
 
@@ -846,46 +918,99 @@ __device__ __forceinline__ void fetch_tile
         int const frame = first + pass * i;
         bool const in_chunk = frame >= 0 && frame + 4 <= call.source_frames;
         bool const in_past = frame + 4 <= 0 && frame >= -chain.history;
+        DRB_GLOBAL float const * const from = in_chunk ? source + frame : past + (in_past ? frame : -4);
 
-        if (PLAIN)
-        {
-            DRB_GLOBAL float const * const from = in_chunk ? source + frame : past + (in_past ? frame : -4);
-
-            fetch.v[i] = *reinterpret_cast<DRB_GLOBAL float4_unaligned const *>(from);
-        }
-        else
-        {
-            fetch.v[i] = *reinterpret_cast<DRB_GLOBAL float4_unaligned const *>(past + (in_past ? frame : -4));
-
-            // the chunk's samples one by one, at frames bent into the chunk
-            if (call.source_frames > 0)
-            {
-                #pragma unroll
-                for (int e = 0; e < 4; e++)
-                {
-                    int const bent = min(max(frame + e, 0), call.source_frames - 1);
-                    long long const index = chunk_index(chain, source_channel_stride, channel, bent);
-
-                    fetch.raw[i][e] = chain.sample_type == kSampleI16 ? static_cast<int>(global_pointer<short const>(call.source)[index])
-                                                                      : global_pointer<int const>(call.source)[index];
-                }
-            }
-        }
+        fetch.v[i] = *reinterpret_cast<DRB_GLOBAL float4_unaligned const *>(from);
     }
 }
 
-template <int FETCH, bool PLAIN>
+// Other sample types and layouts: tiles wholly inside the step's chunk travel
+// as raw words (four frames as one load where they lie together); the first
+// and last tiles of a stream are not fetched ahead but loaded when stored.
+template <int FETCH>
+__device__ __forceinline__ void fetch_tile
+    (
+        Drb_Fast_Chain const & chain, Drb_Device_Call const & call, int base_x,
+        float const *, long long source_channel_stride, int channel, Fetch<FETCH, false> & fetch
+    )
+{
+    typedef int int4_unaligned __attribute__((ext_vector_type(4), aligned(4)));
+    typedef int int2_unaligned __attribute__((ext_vector_type(2), aligned(2)));
+
+    if (!tile_in_chunk<FETCH>(chain, call, base_x)) return;
+
+    int const segment = (threadIdx.x >> 2) & 15, group = (threadIdx.x & 3) + 4 * (threadIdx.x >> 6);
+    int const first = base_x + segment * chain.seg_x + 4 * group - chain.look_x;
+    int const pass = 16 * chain.waves;
+    int const packing = chunk_packing(chain);
+
+    #pragma unroll
+    for (int i = 0; i < FETCH; i++)
+    {
+        int const frame = first + pass * i;
+        long long const index = chunk_index(chain, source_channel_stride, channel, frame);
+
+        // (every path leaves all four words, through one variable each: paths
+        // that wrote different elements would turn the registers into an array
+        // in memory)
+        int w0, w1, w2 = 0, w3 = 0;
+
+        if (packing == 1)
+        {
+            int4_unaligned const four = *reinterpret_cast<DRB_GLOBAL int4_unaligned const *>(global_pointer<short const>(call.source) + (index - channel));
+
+            w0 = four[0]; w1 = four[1]; w2 = four[2]; w3 = four[3];
+        }
+        else if (packing == 2)
+        {
+            int2_unaligned const two = *reinterpret_cast<DRB_GLOBAL int2_unaligned const *>(global_pointer<short const>(call.source) + index);
+
+            w0 = two[0]; w1 = two[1];
+        }
+        else if (packing == 3)
+        {
+            int4_unaligned const four = *reinterpret_cast<DRB_GLOBAL int4_unaligned const *>(global_pointer<int const>(call.source) + index);
+
+            w0 = four[0]; w1 = four[1]; w2 = four[2]; w3 = four[3];
+        }
+        else if (chain.sample_type == kSampleI16)
+        {
+            DRB_GLOBAL short const * const samples = global_pointer<short const>(call.source);
+
+            w0 = samples[chunk_index(chain, source_channel_stride, channel, frame)];
+            w1 = samples[chunk_index(chain, source_channel_stride, channel, frame + 1)];
+            w2 = samples[chunk_index(chain, source_channel_stride, channel, frame + 2)];
+            w3 = samples[chunk_index(chain, source_channel_stride, channel, frame + 3)];
+        }
+        else
+        {
+            DRB_GLOBAL int const * const samples = global_pointer<int const>(call.source);
+
+            w0 = samples[chunk_index(chain, source_channel_stride, channel, frame)];
+            w1 = samples[chunk_index(chain, source_channel_stride, channel, frame + 1)];
+            w2 = samples[chunk_index(chain, source_channel_stride, channel, frame + 2)];
+            w3 = samples[chunk_index(chain, source_channel_stride, channel, frame + 3)];
+        }
+
+        fetch.raw[i][0] = w0;
+        fetch.raw[i][1] = w1;
+        fetch.raw[i][2] = w2;
+        fetch.raw[i][3] = w3;
+    }
+}
+
+template <int FETCH>
 __device__ __forceinline__ void store_tile
     (
         Drb_Fast_Chain const & chain, Drb_Device_Call const & call, Buffers const & buf, int base_x,
-        float const * history, long long source_channel_stride, int channel, Fetch<FETCH, PLAIN> & fetch
+        float const * history, long long source_channel_stride, int channel, Fetch<FETCH, true> & fetch
     )
 {
     int const segment = (threadIdx.x >> 2) & 15, group = (threadIdx.x & 3) + 4 * (threadIdx.x >> 6);
     int const rows = chain.seg_x + chain.look_x;
     int const first = base_x + segment * chain.seg_x + 4 * group - chain.look_x;
     int const pass = 16 * chain.waves;
-    bool const inside = PLAIN && tile_in_chunk<FETCH>(chain, call, base_x);   // no seams: as decided for the fetch
+    bool const inside = tile_in_chunk<FETCH>(chain, call, base_x);   // no seams: as decided for the fetch
     float * const mine = buf.x + cell(4 * group, segment);
 
     #pragma unroll
@@ -895,12 +1020,6 @@ __device__ __forceinline__ void store_tile
         // it: no load may look pending once the tile is stored
         asm volatile ("" : "+v"(fetch.v[i]));
 
-        if (!PLAIN)
-        {
-            #pragma unroll
-            for (int e = 0; e < 4; e++) asm volatile ("" : "+v"(fetch.raw[i][e]));
-        }
-
         if (pass * i >= rows) continue;
 
         int const frame = first + pass * i;
@@ -908,19 +1027,13 @@ __device__ __forceinline__ void store_tile
         bool const in_past = !inside && frame + 4 <= 0 && frame >= -chain.history;
         float4_t & value = fetch.v[i];
 
-        if (!PLAIN && in_chunk)
-        {
-            #pragma unroll
-            for (int e = 0; e < 4; e++) value[e] = raw_sample(fetch.raw[i][e], chain.sample_type);
-        }
-
         // groups of four frames across a seam or an end: one by one
         if (!in_chunk && !in_past)
         {
             #pragma unroll
             for (int e = 0; e < 4; e++)
             {
-                value[e] = source_frame<PLAIN>(chain, call, history, source_channel_stride, channel, frame + e);
+                value[e] = source_frame<true>(chain, call, history, source_channel_stride, channel, frame + e);
             }
 
             asm volatile ("" : "+v"(value));   // as above
@@ -938,6 +1051,77 @@ __device__ __forceinline__ void store_tile
             {
                 if (4 * group + pass * i + e < rows) mine[16 * (pass * i + e)] = value[e];
             }
+        }
+    }
+}
+
+template <int FETCH>
+__device__ __forceinline__ void store_tile
+    (
+        Drb_Fast_Chain const & chain, Drb_Device_Call const & call, Buffers const & buf, int base_x,
+        float const * history, long long source_channel_stride, int channel, Fetch<FETCH, false> & fetch
+    )
+{
+    int const rows = chain.seg_x + chain.look_x;
+
+    #pragma unroll
+    for (int i = 0; i < FETCH; i++)
+    {
+        #pragma unroll
+        for (int e = 0; e < 4; e++) asm volatile ("" : "+v"(fetch.raw[i][e]));   // counts as used, whatever follows
+    }
+
+    if (!tile_in_chunk<FETCH>(chain, call, base_x))
+    {
+        // stream edges and history: one sample at a time, straight into LDS
+        #pragma unroll 1
+        for (int i = threadIdx.x; i < 16 * rows; i += blockDim.x)
+        {
+            int const segment = i & 15, row = i >> 4;
+
+            buf.x[i] = source_frame<false>(chain, call, history, source_channel_stride, channel,
+                                           base_x + segment * chain.seg_x + row - chain.look_x);
+        }
+
+        return;
+    }
+
+    int const segment = (threadIdx.x >> 2) & 15, group = (threadIdx.x & 3) + 4 * (threadIdx.x >> 6);
+    int const pass = 16 * chain.waves;
+    int const packing = chunk_packing(chain);
+    float * const mine = buf.x + cell(4 * group, segment);
+
+    #pragma unroll
+    for (int i = 0; i < FETCH; i++)
+    {
+        if (pass * i >= rows) continue;
+
+        // (branches, not selects between array elements: those would turn the
+        // registers into an array in memory)
+        int word [4];
+
+        if (packing == 1)
+        {
+            #pragma unroll
+            for (int e = 0; e < 4; e++) word[e] = channel ? fetch.raw[i][e] >> 16 : (fetch.raw[i][e] << 16) >> 16;
+        }
+        else if (packing == 2)
+        {
+            word[0] = (fetch.raw[i][0] << 16) >> 16;
+            word[1] = fetch.raw[i][0] >> 16;
+            word[2] = (fetch.raw[i][1] << 16) >> 16;
+            word[3] = fetch.raw[i][1] >> 16;
+        }
+        else
+        {
+            #pragma unroll
+            for (int e = 0; e < 4; e++) word[e] = fetch.raw[i][e];
+        }
+
+        #pragma unroll
+        for (int e = 0; e < 4; e++)
+        {
+            if (4 * group + pass * i + e < rows) mine[16 * (pass * i + e)] = raw_sample(word[e], chain.sample_type);
         }
     }
 }

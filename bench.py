@@ -28,6 +28,8 @@ WORKLOADS = {
     "headline_poor": (44100, 48000, 2, 256, 16, 0, 0, "f32", "planar", 1024),
     "headline_best": (44100, 48000, 2, 256, 16, 0, 3, "f32", "planar", 1024),
     "cfg2_i16": (48000, 44100, 2, 256, 16, 0, 2, "i16", "interleaved", 1024),
+    "cfg2_f32": (48000, 44100, 2, 256, 16, 0, 2, "f32", "planar", 1024),
+    "cfg2_i16_planar": (48000, 44100, 2, 256, 16, 0, 2, "i16", "planar", 1024),
     "cfg3_8ch": (96000, 48000, 8, 256, 16, 0, 2, "f32", "planar", 512),
     "cfg4_mono_pull": (16000, 48000, 1, 256, 16, 1, 2, "f32", "planar", 8192),
     "cfg5_i32_best": (192000, 44100, 2, 256, 16, 0, 3, "i32", "interleaved", 256),
