@@ -508,7 +508,16 @@ DrbAmd_Status drb_amd_batch_create (DrbAmd_Batch_Config const * config, DrbAmd_B
     /* timing diagnostics only: skip phases of the fast kernel (results are wrong) */
     char const * const ablate = getenv("DRB_AMD_FAST_ABLATE");
 
-    for (int i = 0; i < batch->launch_count; i++) batch->launches[i].fast.ablate = ablate ? atoi(ablate) : 0;
+    char const * const stride = getenv("DRB_AMD_FAST_TILE_STRIDE");
+    char const * const no_carry = getenv("DRB_AMD_FAST_NO_CARRY");
+
+    for (int i = 0; i < batch->launch_count; i++)
+    {
+        batch->launches[i].fast.ablate = ablate ? atoi(ablate) : 0;
+        batch->launches[i].fast.tile_stride = stride ? atoi(stride) : 0;
+        batch->launches[i].fast.no_carry = no_carry ? atoi(no_carry) : 0;
+        batch->launches[i].fast.rebuild_tiles = getenv("DRB_AMD_FAST_REBUILD_TILES") ? atoi(getenv("DRB_AMD_FAST_REBUILD_TILES")) : 0;
+    }
 
     size_t const n = (size_t)config->stream_count;
 

@@ -64,6 +64,9 @@ typedef struct Drb_Fast_Chain
 {
     int usable;
     int ablate;                             /* diagnostic: bit mask of phases to skip (timing only) */
+    int tile_stride;                        /* diagnostic: tiles between a workgroup's tiles (0: chosen by the launcher) */
+    int rebuild_tiles;                      /* tiles of a stream between exact rebuilds of the sinc coefficients (0: the kernel's default) */
+    int no_carry;                           /* diagnostic: every tile warms up on its own segment 0 */
     int channels, sample_type, layout, history;   /* sample_type, layout: of the source */
     int target_sample_type, target_layout;
     int has_up, up_taps, up_table;          /* half-band in front of the sinc stage   */

@@ -42,7 +42,12 @@ namespace
 constexpr int kMaxThreads = 320;     // four or five waves, whichever deals the row blocks out more evenly
 constexpr int kBankTapStride = 65;    // floats between taps in the LDS copy of the sinc bank
 constexpr int kMaxTypes = 3;         // row-block types a wave keeps sinc coefficients for
-constexpr int kRebuild = 32;          // tiles of a stream between exact rebuilds of those coefficients
+// Tiles of a stream between exact rebuilds of those coefficients.  Measured on 4 s
+// of noise, 44.1 -> 48 kHz good, worst |error| against upstream: 4.8e-7 rebuilding
+// every tile or every 8, 7.2e-7 every 16, 9.5e-7 every 32, 1.7e-6 (over the
+// bound) every 64 (tools/drift_probe.py).  20 leaves a stream of 19 tiles (1 s at
+// 48 kHz) with one rebuild, in its middle.
+constexpr int kRebuild = 20;
 
 enum { kSampleF32 = 0, kSampleI16 = 1, kSampleI32 = 2 };
 enum { kPlanar = 0, kInterleaved = 1 };
@@ -267,7 +272,9 @@ __device__ __forceinline__ float4_t multiply (float const (& a) [STEPS], float c
 
 struct Tile
 {
-    int index;
+    int index;       // which of the workgroup's tiles (0 = its first)
+    int segment;     // index of the tile's segment 0: target frames [segment seg_y, (segment + 1) seg_y)
+    int first_column;// 1: segment 0 only warms the filters up; 0: its lookback came from the tile before
     int base_y;      // target index of (segment 0, row 0)
     int base_x;      // source index of (segment 0, row 0)
     float drift;     // sub-sample position now minus at the last exact build
@@ -384,6 +391,7 @@ struct Sinc_Type
 struct Sinc_Anchor
 {
     long long rest;    // phase of that row minus the source frames it has consumed
+    int segment;       // the anchor tile's segment 0
     int base_s, base_u, base_x;
 };
 
@@ -635,7 +643,7 @@ __device__ __forceinline__ void write_sinc
     }
     else
     {
-        if (lane.column < 1) return;
+        if (lane.column < tile.first_column) return;
 
         if (PLAIN && whole && tile.inside)
         {
@@ -1211,11 +1219,11 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_fast_kernel
 
     int const delay_behind = chain.delay_place == 1 ? call.delay : 0;
     int const delay_front = chain.delay_place == 2 ? call.delay : 0;
-    // how far the sub-sample position moves from one tile of the stream to the
-    // next, on top of the whole periods the tile advances by
-    float const drift_per_tile = static_cast<float>(static_cast<double>(
-          static_cast<long long>((DOWN_STEPS ? 2 : 1) * chain.tile_frames) * chain.target_delta
-        - static_cast<long long>(15 * chain.seg_u) * chain.source_delta) * chain.scale);
+    // how far the sub-sample position moves from one segment to the next, on top
+    // of the whole periods a segment is long
+    float const drift_per_segment = static_cast<float>(static_cast<double>(
+          static_cast<long long>(chain.seg_s) * chain.target_delta
+        - static_cast<long long>(chain.seg_u) * chain.source_delta) * chain.scale);
 
     // this wave's run of the fractional stage's row-block chains
     int const chains = chain.blocks * chain.periods;
@@ -1228,9 +1236,21 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_fast_kernel
 #endif
 
     Sinc_Type<SINC_STEPS> types [kMaxTypes];
-    Sinc_Anchor anchor = { 0, 0, 0, 0 };
+    Sinc_Anchor anchor = { 0, 0, 0, 0, 0 };
     // of this workgroup's tiles, which lie tile_stride apart
-    int const rebuild_every = max(1, kRebuild / tile_stride);
+    // (a walk over all of a stream's tiles spreads its rebuilds evenly: 19 tiles
+    // are one stretch of 19, not 16 + 3)
+    int rebuild_every = max(1, (chain.rebuild_tiles > 0 ? chain.rebuild_tiles : kRebuild) / tile_stride);
+
+    if (tile_stride == 1 && !chain.no_carry && chain.rebuild_tiles <= 0)
+    {
+        int const segments = (call.target_frames + chain.seg_y - 1) / chain.seg_y;
+        int const tiles = segments > 15 ? 1 + (segments - 15 + 15) / 16 : 1;
+        int const stretches = (tiles + kRebuild - 1) / kRebuild;
+
+        rebuild_every = (tiles + stretches - 1) / stretches;
+    }
+
 
     float applied_drift = 0.0f;
     int since_build = rebuild_every;
@@ -1238,25 +1258,34 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_fast_kernel
 
     // Places tile `index`: from the exact phase every kRebuild tiles, by whole
     // periods in between.
+    // A workgroup that walks over ALL tiles of its stream (tile_stride 1) hands
+    // the tail of each tile's last segment on to the next tile as the lookback of
+    // its segment 0, so that only the stream's first tile spends a segment on
+    // warming up; otherwise every tile does.
+    bool const carry = tile_stride == 1 && !chain.no_carry;
+    int const rebuild_span = rebuild_every * (carry ? 16 : 15 * tile_stride);   // segments between rebuilds
+
     auto place = [&] (int index) -> Tile
     {
         Tile tile;
 
         tile.index = index;
-
-        // segment 1 starts at the tile's first target frame
-        tile.base_y = index * chain.tile_frames - chain.seg_y;
+        tile.first_column = carry && index > 0 ? 0 : 1;
+        tile.segment = carry ? (index > 0 ? 16 * index - 1 : -1) : 15 * (first_tile + index * tile_stride) - 1;
+        tile.base_y = tile.segment * chain.seg_y;
         tile.inside = tile.base_y + 16 * chain.seg_y <= call.target_frames;
         tile.rebuild = since_build >= rebuild_every;
         tile.drift = 0.0f;
 
         if (tile.rebuild)
         {
-            // The coefficients are built for the tile half way to the next
+            // The coefficients are built for a tile half way to the next
             // rebuild, so that the drift they follow is at most half as long.
             // Window ends of that tile's middle segment (8) define the phases
             // of all segments.
-            int const anchor_y = (index + (rebuild_every / 2) * tile_stride) * chain.tile_frames - chain.seg_y;
+            anchor.segment = tile.segment + rebuild_span / 2;
+
+            int const anchor_y = anchor.segment * chain.seg_y;
             int const anchor_s = (DOWN_STEPS ? 2 * anchor_y : anchor_y) - delay_behind;
             int consumed;
             double unused;
@@ -1277,14 +1306,13 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_fast_kernel
             since_build = 0;
         }
 
-        // Tiles lie whole periods from the anchor on every edge, and the phase's
-        // departure from that is the drift the coefficients follow: the same
-        // step from each of the workgroup's tiles to the next.
+        // Segments lie whole periods from the anchor on every edge, and the
+        // phase's departure from that is the drift the coefficients follow.
         {
-            int const tiles = (since_build - rebuild_every / 2) * tile_stride;
+            int const segments = tile.segment - anchor.segment;
 
-            tile.base_x = anchor.base_x + tiles * 15 * chain.seg_x;
-            tile.drift = static_cast<float>(tiles) * drift_per_tile;
+            tile.base_x = anchor.base_x + segments * chain.seg_x;
+            tile.drift = static_cast<float>(segments) * drift_per_segment;
         }
 
         since_build += 1;
@@ -1292,8 +1320,16 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_fast_kernel
         return tile;
     };
 
+    // whether the workgroup's tile `index` has any target frame to write
+    auto has_work = [&] (int index) -> bool
+    {
+        int const first_segment = carry ? (index > 0 ? 16 * index - 1 : 0) : 15 * (first_tile + index * tile_stride);
+
+        return first_segment * chain.seg_y < call.target_frames;
+    };
+
     // ---- tiles of this stream and channel ------------------------------------------
-    Tile tile = place(first_tile);
+    Tile tile = place(0);
 
     if (!ABLATED(1))
     {
@@ -1316,8 +1352,8 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_fast_kernel
 
         STAMP(2);
 
-        int const next_index = tile.index + tile_stride;
-        bool const more = next_index * chain.tile_frames < call.target_frames;
+        int const next_index = tile.index + 1;
+        bool const more = has_work(next_index);
         Tile next = tile;
         Sinc_Anchor const build_anchor = anchor;   // placing the next tile may move the anchor on
 
@@ -1376,6 +1412,24 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_fast_kernel
 
         STAMP(4);
 
+        // The tail of the last tile's last segment becomes the lookback of this
+        // tile's segment 0 in front of the decimator (nobody touches the planes of
+        // d between the barrier above and the sinc stage's first store).
+        if (DOWN_STEPS > 0 && tile.first_column == 0)
+        {
+            int const half = chain.seg_s >> 1;
+
+            for (int i = threadIdx.x; i < 2 * chain.look_d; i += blockDim.x)
+            {
+                float * const plane = i < chain.look_d ? buf.d_odd : buf.d_even;
+                int const row = i < chain.look_d ? i : i - chain.look_d;
+
+                plane[cell(row, 0)] = plane[cell(half + row, 15)];
+            }
+
+            if (UP_STEPS == 0) __syncthreads();   // no barrier of an up-sampler's before the sinc stage stores
+        }
+
 
         if (UP_STEPS > 0)
         {
@@ -1430,6 +1484,14 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_fast_kernel
         // The next tile's rows have long arrived; they go to LDS here rather
         // than at the top of the loop, where waiting for them would also wait
         // for the stores of the down-sampler below.
+        // likewise the tail of the up-sampler's odd plane, for the next tile
+        // (nobody touches that plane between the barrier above and the next
+        // tile's up-sampler)
+        if (UP_STEPS > 0 && more && next.first_column == 0)
+        {
+            for (int i = threadIdx.x; i < chain.look_u; i += blockDim.x) buf.u[cell(i, 0)] = buf.u[cell(chain.seg_x + i, 15)];
+        }
+
         if (!ABLATED(1))
         {
             store_tile(chain, call, buf, next.base_x, stream_history, source_channel_stride, channel, fetch);
@@ -1443,7 +1505,7 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_fast_kernel
 
             load_rows<DOWN_STEPS ? DOWN_STEPS : 1, 4>(a_down_lane, a_down);
             stage_down<DOWN_STEPS ? DOWN_STEPS : 1, PLAIN>
-                (chain, call, tile, buf, lane, target_lane, channel, target_channel_stride, wave, a_down);
+                (chain, call, tile, buf, lane, target_lane, channel, target_channel_stride, wave, a_down, tile.first_column);
         }
 
         STAMP(9);
@@ -1925,6 +1987,7 @@ extern "C" int drb_hip_launch_fast
     long long const pairs = static_cast<long long>(stream_count) * chain->channels;
     long long tile_stride = (2048 + pairs - 1) / pairs;
 
+    if (chain->tile_stride > 0) tile_stride = chain->tile_stride;
     if (tile_stride > max_tiles) tile_stride = max_tiles;
     if (tile_stride < 1) tile_stride = 1;
 

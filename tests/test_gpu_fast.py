@@ -73,8 +73,14 @@ def test_fast_mode_within_tolerance_of_golden(name):
         runner.close()
 
 
-def test_fast_mode_long_stream_many_tiles():
-    """Several tiles per step and several steps: 4 s of noise and of sweep."""
+@pytest.mark.parametrize("stride", ["", "1"])
+def test_fast_mode_long_stream_many_tiles(stride, monkeypatch):
+    """Several tiles per step and several steps: 4 s of noise and of sweep; with
+    the launcher's choice of how workgroups share a stream's tiles and with one
+    workgroup walking over all of them (which hands each tile's tail on to the
+    next instead of warming every tile up)."""
+    if stride:
+        monkeypatch.setenv("DRB_AMD_FAST_TILE_STRIDE", stride)
     for signal in ("noise", "sweep"):
         ch, frames = 2, 4 * 44100
         x = support.white_noise(ch, frames, 21) if signal == "noise" else support.log_sweep(ch, frames, 44100, 0.45 * 44100)
@@ -89,7 +95,7 @@ def test_fast_mode_long_stream_many_tiles():
             got = runner.result(s)
             assert got.shape == want.shape
             worst = assert_close(got, want, "%s stream %d" % (signal, s))
-            assert worst < 6e-7
+            assert worst < 8e-7   # 4.8e-7 with coefficients rebuilt for every tile, 7.2e-7 following the drift over 16
         runner.close()
 
 
