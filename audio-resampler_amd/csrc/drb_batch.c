@@ -80,6 +80,19 @@ struct DrbAmd_Batch
     size_t feed_source_bytes, feed_target_bytes;                   /* per slot */
     void * feed_in [host_slots], * feed_done [host_slots], * feed_out [host_slots]; /* events */
 
+    /* collapsed launch (the one with the sinc stage, if its geometry allows):
+     * coefficient sets for the distinct phases of a step, and which one every
+     * stretch of every stream uses */
+    Drb_Collapse_Job * collapse_jobs;          /* device                       */
+    Drb_Collapse_Spot * collapse_spots;        /* device                       */
+    unsigned int * collapse_sets;              /* device                       */
+    float * collapse_zeros;                    /* device: silence for loads that have no source */
+    size_t collapse_jobs_room, collapse_spots_room, collapse_sets_room;   /* elements / words */
+    void * collapse_host [ring_slots];         /* pinned: spots, then jobs     */
+    size_t collapse_host_bytes [ring_slots];
+    int * collapse_hash;                       /* host scratch                 */
+    size_t collapse_hash_room;
+
     int timing;                       /* bracket the cascade kernel with events */
     void * kernel_start, * kernel_stop;
     int kernel_timed;
@@ -294,6 +307,19 @@ static int build_launches (DrbAmd_Batch_Config const * config, Drb_Plan const * 
         launch->fast.history = geometry.history_frames;
 
         if (!launch->fast.usable || !drb_hip_fast_kernel_exists(&launch->fast)) return 0;
+
+        /* [up] sinc [down] as one filter where that form applies: an experiment,
+         * asked for with DRB_AMD_FAST_COLLAPSED=1 (the three stages are the faster
+         * kernel so far) */
+        if (launch->has_sinc && getenv("DRB_AMD_FAST_COLLAPSED") && atoi(getenv("DRB_AMD_FAST_COLLAPSED")))
+        {
+            Drb_Fast_Chain collapsed = launch->fast;
+
+            if (drb_plan_collapse_geometry(&collapsed, fast_lds_budget) && drb_hip_fast_kernel_exists(&collapsed))
+            {
+                launch->fast = collapsed;
+            }
+        }
     }
 
     return count;
@@ -311,6 +337,12 @@ static double issued_flops (Fast_Launch const * launches, int count)
         /* 16 x 16 x 4 products of 2048 flop each, per tile of one channel */
         long const up_blocks = fast->has_up ? (fast->seg_x + 15) / 16 : 0;
         long const down_blocks = fast->has_down ? (fast->seg_y + 15) / 16 : 0;
+        if (fast->kind == 3)
+        {
+            total += 2048.0 * (double)fast->blocks * fast->ksteps / (double)fast->tile_frames * launches[i].rate_ratio;
+            continue;
+        }
+
         long const products = up_blocks * ((fast->up_taps + 16) / 4)
                             + (long)fast->blocks * fast->periods * fast->ksteps * (fast->column_drift != 0.0f ? 2 : 1)
                             + down_blocks * ((fast->down_taps + 16) / 4);
@@ -365,6 +397,8 @@ DrbAmd_Status drb_amd_plan_info (DrbAmd_Batch_Config const * config, DrbAmd_Plan
     info->fast_launches = count;
     info->fast_tile_frames = count > 0 ? launches[count - 1].fast.tile_frames : 0;
     info->fast_issued_flops_per_output_sample = issued_flops(launches, count);
+
+    for (int i = 0; i < count; i++) if (launches[i].fast.kind == 3) info->fast_collapsed = 1;
 
     free(launches);
 
@@ -440,6 +474,14 @@ static void release (DrbAmd_Batch * batch)
         if (batch->launches[i].history[1]) drb_hip_free(batch->launches[i].history[1]);
         if (batch->launches[i].output) drb_hip_free(batch->launches[i].output);
     }
+
+    for (int i = 0; i < ring_slots; i++) if (batch->collapse_host[i]) drb_hip_host_free(batch->collapse_host[i]);
+
+    if (batch->collapse_jobs) drb_hip_free(batch->collapse_jobs);
+    if (batch->collapse_spots) drb_hip_free(batch->collapse_spots);
+    if (batch->collapse_sets) drb_hip_free(batch->collapse_sets);
+    if (batch->collapse_zeros) drb_hip_free(batch->collapse_zeros);
+    free(batch->collapse_hash);
 
     if (batch->kernel_start) drb_hip_event_destroy(batch->kernel_start);
     if (batch->kernel_stop) drb_hip_event_destroy(batch->kernel_stop);
@@ -561,6 +603,8 @@ DrbAmd_Status drb_amd_batch_create (DrbAmd_Batch_Config const * config, DrbAmd_B
         if (!code) code = drb_hip_alloc((void **)&batch->launches[i].history[1], bytes);
     }
 
+    if (!code) code = drb_hip_alloc((void **)&batch->collapse_zeros, 256);
+    if (!code) code = drb_hip_memset_async(batch->collapse_zeros, 0, 256, 0);
     if (!code) code = drb_hip_memset_async(batch->fault_device, 0, fault_words * sizeof(long long), 0);
 
     if (code)
@@ -661,6 +705,166 @@ DrbAmd_Status drb_amd_batch_query (DrbAmd_Batch const * batch, int const * frame
 
         counts[s] = pull ? step.source_frames : step.target_frames;
     }
+
+    return drb_amd_ok;
+}
+
+/* ---- collapsed launch: which coefficient sets a step needs ------------------- */
+
+static int collapse_grow_device (void ** pointer, size_t * room, size_t wanted, size_t element, void * hip_stream)
+{
+    if (wanted <= *room) return 0;
+
+    int code = drb_hip_stream_synchronize(hip_stream);   /* earlier steps may still read the old one */
+
+    if (code) return code;
+    if (*pointer) drb_hip_free(*pointer);
+
+    *pointer = 0;
+    *room = 0;
+    wanted += wanted / 2 + 16;
+
+    if ((code = drb_hip_alloc(pointer, wanted * element)) != 0) return code;
+
+    *room = wanted;
+
+    return 0;
+}
+
+/* Lays the step of every stream out in stretches of tiles, finds the distinct
+ * phases among their anchors (streams that run in step share them), and sends
+ * the jobs and the per-stretch table to the device.  The kernel lays the
+ * stretches out by the same rule (drb_collapsed.inc). */
+static DrbAmd_Status collapse_prepare
+    (
+        DrbAmd_Batch * batch, Fast_Launch const * launch, Drb_Device_Call const * calls, int slot,
+        void * hip_stream, int * max_stretches_out, int * job_count_out
+    )
+{
+    Drb_Fast_Chain const * const fast = &launch->fast;
+    int const n = batch->config.stream_count;
+    int const wanted = fast->rebuild_tiles > 0 ? fast->rebuild_tiles : drb_collapse_rebuild_tiles;
+    int max_stretches = 1, code;
+    size_t total = 0;
+
+    for (int s = 0; s < n; s++)
+    {
+        int const tiles = (calls[s].target_frames + fast->tile_frames - 1) / fast->tile_frames;
+        int const stretches = (tiles + wanted - 1) / wanted;
+
+        if (stretches > max_stretches) max_stretches = stretches;
+        total += (size_t)stretches;
+    }
+
+    size_t const spots_bytes = (size_t)n * max_stretches * sizeof(Drb_Collapse_Spot);
+    size_t const host_bytes = spots_bytes + (total + 1) * sizeof(Drb_Collapse_Job);
+
+    if (host_bytes > batch->collapse_host_bytes[slot])
+    {
+        if (batch->collapse_host[slot]) drb_hip_host_free(batch->collapse_host[slot]);
+
+        batch->collapse_host[slot] = 0;
+        batch->collapse_host_bytes[slot] = 0;
+
+        if ((code = drb_hip_host_alloc(&batch->collapse_host[slot], host_bytes + host_bytes / 2)) != 0)
+        {
+            return fail(drb_amd_error_out_of_memory, "pinned memory for the coefficient jobs: %s", drb_hip_error_text(code));
+        }
+
+        batch->collapse_host_bytes[slot] = host_bytes + host_bytes / 2;
+    }
+
+    size_t hash_size = 64;
+
+    while (hash_size < 2 * total + 2) hash_size *= 2;
+
+    if (hash_size > batch->collapse_hash_room)
+    {
+        free(batch->collapse_hash);
+        batch->collapse_hash = malloc(hash_size * sizeof(int));
+        batch->collapse_hash_room = batch->collapse_hash ? hash_size : 0;
+
+        if (!batch->collapse_hash) return fail(drb_amd_error_out_of_memory, "out of host memory");
+    }
+
+    memset(batch->collapse_hash, 0, hash_size * sizeof(int));
+
+    Drb_Collapse_Spot * const spots = batch->collapse_host[slot];
+    Drb_Collapse_Job * const jobs = (Drb_Collapse_Job *)((char *)batch->collapse_host[slot] + spots_bytes);
+    int job_count = 0;
+
+    for (int s = 0; s < n; s++)
+    {
+        Drb_Device_Call const * const call = &calls[s];
+        Drb_Collapse_Spot * const row = spots + (size_t)s * max_stretches;
+        int const tiles = (call->target_frames + fast->tile_frames - 1) / fast->tile_frames;
+        int const stretches = (tiles + wanted - 1) / wanted;
+        int const every = stretches > 0 ? (tiles + stretches - 1) / stretches : 1;
+
+        /* streams that run in step: the same stretches */
+        if (s > 0 && call->phase == call[-1].phase && call->delay == call[-1].delay
+            && call->target_frames == call[-1].target_frames)
+        {
+            memcpy(row, row - max_stretches, (size_t)max_stretches * sizeof(Drb_Collapse_Spot));
+            continue;
+        }
+
+        for (int j = 0; j < max_stretches; j++)
+        {
+            if (j >= stretches) { row[j].job = 0; row[j].base_x = 0; continue; }
+
+            long long rest, frame;
+            int parity;
+
+            drb_plan_collapse_key(fast, call->phase, call->delay, 16LL * j * every + 8LL * every, &rest, &parity, &frame);
+
+            unsigned long long const mixed = ((unsigned long long)rest * 2 + (unsigned)parity) * 0x9E3779B97F4A7C15ULL;
+            size_t at = (size_t)(mixed >> 20) & (hash_size - 1);
+            int found = -1;
+
+            while (batch->collapse_hash[at])
+            {
+                Drb_Collapse_Job const * const other = &jobs[batch->collapse_hash[at] - 1];
+
+                if (other->rest == rest && other->parity == parity) { found = batch->collapse_hash[at] - 1; break; }
+
+                at = (at + 1) & (hash_size - 1);
+            }
+
+            if (found < 0)
+            {
+                if (!drb_plan_collapse_job(fast, rest, parity, &jobs[job_count]))
+                {
+                    return fail(drb_amd_error_device, "stream %d: filter windows do not fit the kernel's geometry", s);
+                }
+
+                found = job_count++;
+                batch->collapse_hash[at] = found + 1;
+            }
+
+            long long const base = frame + jobs[found].origin;
+
+            if (base < -0x40000000LL || base > 0x40000000LL) return fail(drb_amd_error_bad_argument, "stream %d: step too long", s);
+
+            row[j].job = found;
+            row[j].base_x = (int)base;
+        }
+    }
+
+    code = collapse_grow_device((void **)&batch->collapse_spots, &batch->collapse_spots_room, (size_t)n * max_stretches, sizeof(Drb_Collapse_Spot), hip_stream);
+    if (!code) code = collapse_grow_device((void **)&batch->collapse_jobs, &batch->collapse_jobs_room, (size_t)job_count + 1, sizeof(Drb_Collapse_Job), hip_stream);
+    if (!code) code = collapse_grow_device((void **)&batch->collapse_sets, &batch->collapse_sets_room,
+                                           ((size_t)job_count + 1) * (size_t)drb_hip_collapse_set_words(fast), sizeof(unsigned int), hip_stream);
+
+    if (code) return fail(drb_amd_error_out_of_memory, "coefficient sets: %s", drb_hip_error_text(code));
+
+    code = drb_hip_upload_async(batch->collapse_spots, spots, spots_bytes, hip_stream);
+    if (!code && job_count > 0) code = drb_hip_upload_async(batch->collapse_jobs, jobs, (size_t)job_count * sizeof(Drb_Collapse_Job), hip_stream);
+
+    if (code) return fail_hip("coefficient jobs upload", code);
+
+    *max_stretches_out = max_stretches;
+    *job_count_out = job_count;
 
     return drb_amd_ok;
 }
@@ -799,6 +1003,19 @@ DrbAmd_Status drb_amd_batch_process
     float * const history_out = batch->history[current ^ 1];
     int const tile = batch->geometry.tile_frames;
 
+    int collapse_stretches = 1, collapse_job_count = 0;
+
+    for (int l = 0; l < launches; l++)
+    {
+        if (fast && batch->launches[l].fast.kind == 3)
+        {
+            DrbAmd_Status const status = collapse_prepare(batch, &batch->launches[l], calls + (size_t)l * n, slot, hip_stream,
+                                                          &collapse_stretches, &collapse_job_count);
+
+            if (status != drb_amd_ok) return status;
+        }
+    }
+
     code = drb_hip_upload_async(batch->calls_device, calls, (size_t)n * launches * sizeof(Drb_Device_Call), hip_stream);
 
     if (!code && batch->timing) code = drb_hip_event_record(batch->kernel_start, hip_stream);
@@ -813,7 +1030,20 @@ DrbAmd_Status drb_amd_batch_process
             long long const target_stride = l == launches - 1 ? target_channel_stride : launch->output_frames;
             int const fast_tile = launch->fast.tile_frames;
 
-            code = drb_hip_launch_fast
+            if (launch->fast.kind == 3)
+            {
+                code = drb_hip_launch_collapse_build(&launch->fast, batch->collapse_jobs, collapse_job_count,
+                                                     batch->collapse_sets, batch->fault_device, hip_stream);
+
+                if (!code) code = drb_hip_launch_collapsed
+                (
+                    &launch->fast, launch_calls, n, (int)((most[l] + fast_tile - 1) / fast_tile),
+                    l == 0 ? history_in : launch->history[current], source_stride, target_stride,
+                    batch->collapse_jobs, batch->collapse_spots, collapse_stretches, batch->collapse_sets,
+                    batch->collapse_zeros, batch->fault_device, hip_stream
+                );
+            }
+            else code = drb_hip_launch_fast
             (
                 &launch->fast, launch_calls, n, (int)((most[l] + fast_tile - 1) / fast_tile),
                 l == 0 ? history_in : launch->history[current], source_stride, target_stride,

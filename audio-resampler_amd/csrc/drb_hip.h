@@ -84,16 +84,48 @@ typedef struct Drb_Fast_Chain
     int off_x, off_u, off_d_odd, off_d_even; /* LDS float offsets                      */
     int off_bank;                           /* sinc bank while coefficients are rebuilt: shares the planes of d where a down-sampler exists */
     int off_taps;                           /* half-band taps, zero-padded: up, then down */
-    int kind;                               /* 0: [up] sinc [down]; 1: one half-band decimator on its own; 2: one interpolator */
+    int kind;                               /* 0: [up] sinc [down]; 1: one half-band decimator on its own; 2: one interpolator;
+                                               3: [up] sinc [down] collapsed into one time-varying filter (see Drb_Collapse_Job) */
     int waves;                              /* waves per workgroup: 4 or 5, whichever deals the row blocks out more evenly */
     float column_drift;                     /* sub-sample position of segment c minus segment c - 1 (0: too small to matter) */
     int types_per_wave;                     /* row-block types one wave keeps coefficients for */
+    int plane_stride, plane_rows;           /* kind 3, planar float32: floats between segments of a source plane in LDS
+                                               ([segment][row], filled by global-to-LDS loads), and floats loaded per segment */
     int lds_floats;
     int tile_frames;                        /* target frames per tile = 15 * seg_y    */
     long long source_delta, target_delta;
     double scale;
 }
 Drb_Fast_Chain;
+
+/* Collapsed chains (kind 3).  [up2x] -> sinc -> [down2x] is one linear map from
+ * source frames to target frames whose rows repeat every period of the rate
+ * ratio (up to the drift of the fixed-point phase), so a segment of seg_y
+ * target frames is ONE banded product: `blocks` row blocks of 16 target frames,
+ * each over a window of 4 * ksteps source frames.  The coefficients depend on
+ * the phase only; a set is built on the device for every distinct phase the
+ * host finds among the streams of a step ("job"), for an anchor segment in the
+ * middle of a stretch of `rebuild_tiles` tiles, and every tile of the stretch
+ * uses it, corrected to first order for the drift since the anchor. */
+enum { drb_collapse_max_blocks = 12, drb_collapse_rebuild_tiles = 8 /* tiles per stretch */ };
+
+typedef struct Drb_Collapse_Job
+{
+    long long rest;      /* phase of the anchor segment's first sinc output minus whole source frames: [0, source_delta) */
+    int parity;          /* behind an up-sampler: whether that output's window ends on an odd sinc-input frame           */
+    int origin;          /* source frame, relative to the anchor's, that row look_x of the plane holds                    */
+    int first_row [drb_collapse_max_blocks];   /* LDS row (lookback included) where each row block's window starts    */
+}
+Drb_Collapse_Job;
+
+/* One stretch of one stream: which coefficient set, and the source frame that
+ * row `look_x` of the anchor segment's column holds. */
+typedef struct Drb_Collapse_Spot
+{
+    int job;
+    int base_x;
+}
+Drb_Collapse_Spot;
 
 /* All functions return 0 on success, else a HIP error code. */
 int drb_hip_device_count (int * count);
@@ -139,6 +171,26 @@ int drb_hip_launch_fast
         Drb_Device_Call const * calls, int stream_count, int max_tiles,
         float const * history,
         long long source_channel_stride, long long target_channel_stride,
+        int * fault_flag, void * stream
+    );
+
+/* Collapsed chains: coefficient sets for `job_count` jobs into `sets`
+ * (collapse_set_words(chain) 32-bit words each), then the filter itself:
+ * spots[stream * max_stretches + stretch]. */
+long long drb_hip_collapse_set_words (Drb_Fast_Chain const * chain);
+int drb_hip_launch_collapse_build
+    (
+        Drb_Fast_Chain const * chain, Drb_Collapse_Job const * jobs, int job_count,
+        unsigned int * sets, int * fault_flag, void * stream
+    );
+int drb_hip_launch_collapsed
+    (
+        Drb_Fast_Chain const * chain,
+        Drb_Device_Call const * calls, int stream_count, int max_tiles,
+        float const * history,
+        long long source_channel_stride, long long target_channel_stride,
+        Drb_Collapse_Job const * jobs, Drb_Collapse_Spot const * spots, int max_stretches,
+        unsigned int const * sets, float const * zeros,
         int * fault_flag, void * stream
     );
 

@@ -1165,6 +1165,12 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_fast_kernel
 
     if (first_tile * chain.tile_frames >= call.target_frames) return;
 
+    // LDS arrives as the last workgroup left it, and the zero-padded products
+    // also read rows that nobody writes: they must hold numbers (0 x NaN = NaN)
+    for (int i = threadIdx.x; i < chain.lds_floats; i += blockDim.x) lds[i] = 0.0f;
+
+    __syncthreads();
+
     // the same for all lanes of a wave: kept in a scalar register so that what
     // depends on it branches instead of masking lanes
     int const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1641,6 +1647,12 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_decimate_kernel
 
     if (first_tile * chain.tile_frames >= call.target_frames) return;
 
+    // LDS arrives as the last workgroup left it, and the zero-padded products
+    // also read rows that nobody writes: they must hold numbers (0 x NaN = NaN)
+    for (int i = threadIdx.x; i < chain.lds_floats; i += blockDim.x) lds[i] = 0.0f;
+
+    __syncthreads();
+
     int const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
     Lane lane;
@@ -1754,6 +1766,12 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_interpolate_kernel
 
     if (first_tile * chain.tile_frames >= frames) return;
 
+    // LDS arrives as the last workgroup left it, and the zero-padded products
+    // also read rows that nobody writes: they must hold numbers (0 x NaN = NaN)
+    for (int i = threadIdx.x; i < chain.lds_floats; i += blockDim.x) lds[i] = 0.0f;
+
+    __syncthreads();
+
     int const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
     Lane lane;
@@ -1850,6 +1868,8 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_interpolate_kernel
         __syncthreads();   // the plane may be written again
     }
 }
+
+#include "drb_collapsed.inc"
 
 typedef void Fast_Kernel
     (
@@ -1949,7 +1969,105 @@ Fast_Kernel * pick_kernel (Drb_Fast_Chain const * chain)
 
 extern "C" int drb_hip_fast_kernel_exists (Drb_Fast_Chain const * chain)
 {
-    return pick_kernel(chain) != nullptr;
+    return chain->kind == 3 ? (collapsed_is_plain(chain) ? pick_collapsed_plain(chain) != nullptr : pick_collapsed(chain) != nullptr)
+                            : pick_kernel(chain) != nullptr;
+}
+
+extern "C" long long drb_hip_collapse_set_words (Drb_Fast_Chain const * chain)
+{
+    return collapse_set_words(chain->blocks, chain->ksteps);
+}
+
+extern "C" int drb_hip_launch_collapse_build
+    (
+        Drb_Fast_Chain const * chain, Drb_Collapse_Job const * jobs, int job_count,
+        unsigned int * sets, int * fault_flag, void * stream
+    )
+{
+    if (job_count <= 0) return 0;
+    if (chain->kind != 3 || chain->blocks < 1 || chain->blocks > drb_collapse_max_blocks) return hipErrorInvalidValue;
+
+    size_t const dynamic = static_cast<size_t>(kBuildOutputs) * (kBuildWide + 32) * sizeof(double);
+
+    hipError_t const status = hipFuncSetAttribute
+    (
+        reinterpret_cast<void const *>(drb_collapse_build_kernel),
+        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(dynamic)
+    );
+
+    if (status != hipSuccess) return status;
+
+    drb_collapse_build_kernel<<<dim3(static_cast<unsigned>(job_count), static_cast<unsigned>(chain->blocks), 2), dim3(256), dynamic, static_cast<hipStream_t>(stream)>>>
+    (
+        *chain, jobs, sets, collapse_set_words(chain->blocks, chain->ksteps), fault_flag
+    );
+
+    return hipGetLastError();
+}
+
+extern "C" int drb_hip_launch_collapsed
+    (
+        Drb_Fast_Chain const * chain,
+        Drb_Device_Call const * calls, int stream_count, int max_tiles,
+        float const * history,
+        long long source_channel_stride, long long target_channel_stride,
+        Drb_Collapse_Job const * jobs, Drb_Collapse_Spot const * spots, int max_stretches,
+        unsigned int const * sets, float const * zeros,
+        int * fault_flag, void * stream
+    )
+{
+    if (stream_count <= 0 || max_tiles <= 0) return 0;
+
+    bool const plain = collapsed_is_plain(chain);
+    Collapsed_Kernel * const kernel = plain ? nullptr : pick_collapsed(chain);
+    Collapsed_Plain_Kernel * const plain_kernel = plain ? pick_collapsed_plain(chain) : nullptr;
+
+    if ((!kernel && !plain_kernel) || max_stretches < 1 || (plain && !zeros)) return hipErrorInvalidValue;
+
+    size_t const dynamic = static_cast<size_t>(chain->lds_floats) * sizeof(float);
+
+    if (dynamic > 48 * 1024)
+    {
+        hipError_t const status = hipFuncSetAttribute
+        (
+            plain ? reinterpret_cast<void const *>(plain_kernel) : reinterpret_cast<void const *>(kernel),
+            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(dynamic)
+        );
+
+        if (status != hipSuccess) return status;
+    }
+
+    // a workgroup walks over the tiles of its stream and channel with a stride;
+    // about eight workgroups per CU keep the chip busy
+    long long const pairs = static_cast<long long>(stream_count) * chain->channels;
+    long long tile_stride = (2048 + pairs - 1) / pairs;
+
+    if (chain->tile_stride > 0) tile_stride = chain->tile_stride;
+    if (tile_stride > max_tiles) tile_stride = max_tiles;
+    if (tile_stride < 1) tile_stride = 1;
+
+    long long const blocks = pairs * tile_stride;
+
+    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+
+    if (plain)
+    {
+        plain_kernel<<<dim3(static_cast<unsigned>(blocks)), dim3(static_cast<unsigned>(64 * (chain->waves + 1))), dynamic, static_cast<hipStream_t>(stream)>>>
+        (
+            *chain, calls, stream_count, static_cast<int>(tile_stride), history,
+            source_channel_stride, target_channel_stride, jobs, spots, max_stretches, sets, zeros, fault_flag
+        );
+    }
+    else
+    {
+        kernel<<<dim3(static_cast<unsigned>(blocks)), dim3(static_cast<unsigned>(64 * chain->waves)), dynamic, static_cast<hipStream_t>(stream)>>>
+        (
+            *chain, calls, stream_count, static_cast<int>(tile_stride), history,
+            source_channel_stride, target_channel_stride, jobs, spots, max_stretches, sets, fault_flag
+        );
+    }
+
+    return hipGetLastError();
 }
 
 extern "C" int drb_hip_launch_fast

@@ -922,3 +922,160 @@ int drb_plan_fast_geometry (Drb_Plan const * plan, int lds_budget_bytes, Drb_Fas
 
     return (reach + 3) / 4 * 4;
 }
+
+/* ---- collapsed chains -------------------------------------------------------- */
+
+/* Source frames (of the sinc stage) consumed before sinc output `nu`, counted
+ * from the anchor, whose phase is `rest` past a whole source frame
+ * (drb-audio-converter.c:1617-1648 push, 1677-1707 pull). */
+static long long collapse_window_end (Drb_Fast_Chain const * chain, long long rest, long long nu)
+{
+    long long const phase = rest + nu * chain->target_delta;
+    long long q = floor_div(phase, chain->source_delta);
+
+    if (!chain->sinc_pull && phase - q * chain->source_delta == 0) q -= 1;
+
+    return q;
+}
+
+/* First and one-past-last source frame (relative to the anchor's own) that the
+ * 16 target frames of every row block depend on. */
+static void collapse_extents (Drb_Fast_Chain const * chain, long long rest, int parity, int * lo, int * hi)
+{
+    for (int b = 0; b < chain->blocks; b++)
+    {
+        int const rho0 = 16 * b, rho1 = 16 * b + 15 < chain->seg_y ? 16 * b + 15 : chain->seg_y - 1;
+        long long const nu_lo = chain->has_down ? 2 * (rho0 - chain->down_taps) + 1 : rho0;
+        long long const nu_hi = chain->has_down ? 2 * rho1 - 1 : rho1;
+        long long const e_first = parity + collapse_window_end(chain, rest, nu_lo) - chain->sinc_taps;
+        long long const e_last = parity + collapse_window_end(chain, rest, nu_hi) - 1;
+
+        lo[b] = (int)(chain->has_up ? floor_div(e_first, 2) - chain->up_taps + 1 : e_first);
+        hi[b] = (int)(chain->has_up ? floor_div(e_last - 1, 2) : e_last) + 1;
+    }
+}
+
+int drb_plan_collapse_geometry (Drb_Fast_Chain * chain, int lds_budget_bytes)
+{
+    if (!chain->usable || chain->kind != 0) return 0;
+    if (!chain->has_up && !chain->has_down) return 0;   /* one stage: nothing to collapse */
+    if (chain->column_drift != 0.0f) return 0;
+
+    Drb_Fast_Chain c = *chain;
+
+    /* segment: whole periods of the exact ratio, 128 .. 192 target frames */
+    long long const g = gcd_ll(c.period_in, c.period_out);
+    int const ratio_in = (int)(c.period_in / g), ratio_out = (int)(c.period_out / g);
+    int m = 0;
+
+    for (int k = 1; k <= 4096 && !m; k++)
+    {
+        int const seg_s = ratio_out * k, seg_u = ratio_in * k;
+        int const seg_y = c.has_down ? seg_s / 2 : seg_s;
+
+        if ((c.has_down && (seg_s & 1)) || (c.has_up && (seg_u & 1))) continue;
+        if (seg_y > 192) break;
+        if (seg_y >= 128) m = k;
+    }
+
+    if (!m) return 0;
+
+    c.kind = 3;
+    c.periods = m;
+    c.period_in = ratio_in;
+    c.period_out = ratio_out;
+    c.seg_s = ratio_out * m;
+    c.seg_u = ratio_in * m;
+    c.seg_y = c.has_down ? c.seg_s / 2 : c.seg_s;
+    c.seg_x = c.has_up ? c.seg_u / 2 : c.seg_u;
+    c.blocks = (c.seg_y + 15) / 16;
+
+    if (c.blocks > drb_collapse_max_blocks) return 0;
+
+    /* widest a row block's window gets for any phase: between its first and its
+     * last sinc output the stage consumes floor(d nu ratio) or one more frame */
+    long long const nu_block = c.has_down ? 2 * 15 - 1 - (1 - 2 * c.down_taps) : 15;
+    long long const nu_all = c.has_down ? 2 * (c.seg_y - 1) - 1 - (1 - 2 * c.down_taps) : c.seg_y - 1;
+    long long const span_block = floor_div(nu_block * c.target_delta, c.source_delta) + 1 + c.sinc_taps - 1;
+    long long const span_all = floor_div(nu_all * c.target_delta, c.source_delta) + 1 + c.sinc_taps - 1;
+    int const width = c.has_up ? (int)(span_block >> 1) + c.up_taps : (int)span_block + 1;
+    int const rows = c.has_up ? (int)(span_all >> 1) + c.up_taps : (int)span_all + 1;
+
+    c.ksteps = (width + 3) / 4 | 1;   /* kernel images exist for odd counts */
+    c.look_x = (rows - c.seg_x + 3) / 4 * 4;
+    if (c.look_x < 4) c.look_x = 4;
+    c.look_u = c.look_d = 0;
+
+    c.waves = c.blocks % 5 == 0 || c.blocks == 9 ? 5 : 4;
+    c.types_per_wave = (c.blocks + c.waves - 1) / c.waves;   /* row blocks per wave */
+
+    /* one plane of source rows, [row][16 segments], and a few rows behind it that
+     * only zero coefficients ever meet */
+    c.off_x = 0;
+    c.lds_floats = (c.seg_x + c.look_x + 8) * 16;
+    c.tile_frames = 16 * c.seg_y;
+
+    /* Planar float32 sources go to LDS without passing through registers, four
+     * planes going round, as [segment][row]: rows of one segment are consecutive (a
+     * wave-wide load lands 64 x 16 consecutive bytes), segments 8 .. 15 two rows
+     * later than their place so that the 64 lanes of an operand read (rows quad,
+     * segments 0 .. 15) meet 32 different banks in either half. */
+    c.plane_rows = (c.seg_x + c.look_x + 8 + 2 + 3) / 4 * 4;
+    c.plane_stride = c.plane_rows;
+    while (c.plane_stride % 32 != 4) c.plane_stride++;
+
+    if (4 * 16 * c.plane_stride > c.lds_floats) c.lds_floats = 4 * 16 * c.plane_stride;
+
+    if (c.lds_floats * 4 > lds_budget_bytes) return 0;
+
+    *chain = c;
+
+    return 1;
+}
+
+void drb_plan_collapse_key
+    (
+        Drb_Fast_Chain const * chain, long long phase, int delay, long long anchor_segment,
+        long long * rest, int * parity, long long * frame
+    )
+{
+    int const delay_behind = chain->delay_place == 1 ? delay : 0;
+    int const delay_front = chain->delay_place == 2 ? delay : 0;
+    long long const first = anchor_segment * chain->seg_y;
+    long long const nu = (chain->has_down ? 2 * first : first) - delay_behind;
+    long long const at = phase + nu * chain->target_delta;
+    long long const q = floor_div(at, chain->source_delta);
+    long long const mu = q - delay_front;
+
+    *rest = at - q * chain->source_delta;
+    *parity = chain->has_up ? (int)(mu & 1) : 0;
+    *frame = chain->has_up ? floor_div(mu, 2) : mu;
+}
+
+int drb_plan_collapse_job (Drb_Fast_Chain const * chain, long long rest, int parity, Drb_Collapse_Job * job)
+{
+    int lo [drb_collapse_max_blocks] = { 0 }, hi [drb_collapse_max_blocks] = { 0 };
+
+    memset(job, 0, sizeof(*job));
+
+    job->rest = rest;
+    job->parity = parity;
+
+    collapse_extents(chain, rest, parity, lo, hi);
+
+    job->origin = hi[chain->blocks - 1] - chain->seg_x;   /* row look_x of the plane */
+
+    for (int b = 0; b < chain->blocks; b++)
+    {
+        /* (a window that would run past the plane starts earlier instead: the
+         * last block of a segment may have few rows and a short span) */
+        int const last_start = chain->seg_x + chain->look_x + 8 - 4 * chain->ksteps;
+        int const start = lo[b] - job->origin + chain->look_x;
+
+        job->first_row[b] = start < last_start ? start : last_start;
+
+        if (job->first_row[b] < 0 || hi[b] - lo[b] > 4 * chain->ksteps) return 0;
+    }
+
+    return 1;
+}

@@ -136,6 +136,26 @@ struct Drb_Fast_Chain;
  * fast kernel wants (0 if unusable). */
 int drb_plan_fast_geometry (Drb_Plan const * plan, int lds_budget_bytes, struct Drb_Fast_Chain * chain);
 
+/* Turns a usable [up] sinc [down] geometry into the collapsed form (kind 3: one
+ * banded product per segment, see drb_hip.h); returns 0 and leaves the chain
+ * alone where that form does not apply. */
+int drb_plan_collapse_geometry (struct Drb_Fast_Chain * chain, int lds_budget_bytes);
+
+/* A stretch of a stream's step, whose anchor segment (seg_y target frames each,
+ * counted from the step's first) is `anchor_segment`: what its coefficients
+ * depend on (rest, parity) and the source frame they are counted from. */
+void drb_plan_collapse_key
+    (
+        struct Drb_Fast_Chain const * chain, long long phase, int delay, long long anchor_segment,
+        long long * rest, int * parity, long long * frame
+    );
+
+/* The job that builds the coefficient set of (rest, parity): where every row
+ * block's window starts.  0 if the windows do not fit the geometry (never, for
+ * the bounds the geometry was made from). */
+struct Drb_Collapse_Job;
+int drb_plan_collapse_job (struct Drb_Fast_Chain const * chain, long long rest, int parity, struct Drb_Collapse_Job * job);
+
 #ifdef __cplusplus
 }
 #endif

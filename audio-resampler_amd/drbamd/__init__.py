@@ -51,7 +51,7 @@ class PlanInfo(ctypes.Structure):
                 ("flops_per_output_sample", ctypes.c_double),
                 ("bytes_per_output_sample", ctypes.c_double),
                 ("fast_path", ctypes.c_int), ("fast_tile_frames", ctypes.c_int), ("fast_launches", ctypes.c_int),
-                ("fast_issued_flops_per_output_sample", ctypes.c_double)]
+                ("fast_issued_flops_per_output_sample", ctypes.c_double), ("fast_collapsed", ctypes.c_int)]
 
     def stages(self):
         kinds = {1: "up2x", 2: "down2x", 3: "sinc", 4: "slicer"}

@@ -159,7 +159,7 @@ def main():
     user_rate = dst if direction == 1 else src
     frames = int(round(args.seconds * user_rate / bs)) * bs
     other = batch.query([frames] * streams)[0]
-    source_frames = other + 4096 if direction == 1 else frames
+    source_frames = (other + 4096 if direction == 1 else frames) + int(os.environ.get("BENCH_SOURCE_PAD", "0"))
     target_capacity = frames if direction == 1 else other + 4096
 
     generator = torch.Generator(device=device)

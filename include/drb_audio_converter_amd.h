@@ -323,6 +323,10 @@ typedef struct DrbAmd_Plan_Info
                                banded products and the warm-up segment included;
                                one blended kernel per output instead of upstream's
                                two or four dot products)                          */
+    int fast_collapsed;     /* 1: [up2x] sinc [down2x] run as ONE time-varying filter
+                               from source to target frames (its coefficients are
+                               the product of the three stages', so it spends fewer
+                               multiply-adds per sample than upstream's cascade)   */
 }
 DrbAmd_Plan_Info;
 

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Where the collapsed kernel's waves spend their cycles (diagnostic build only).
+
+Build `make -C audio-resampler_amd/csrc stamps`, then on the GPU box:
+    DRB_AMD_FAST_COLLAPSED=1 DRB_AMD_LIB=audio-resampler_amd/lib/libdrb_audio_converter_amd_stamps.so python3 tools/stamp_collapsed.py
+Prints, per wave of the workgroup, the cycles per tile spent in each phase."""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "audio-resampler_amd"))
+
+import torch
+
+import drbamd
+
+FILTER = ["top", "barrier", "lds", "multiply+write"]
+LOADER = ["issue", "wait", "barrier"]
+
+
+def main():
+    streams, ch, frames = 1024, 2, 44032
+    config = drbamd.make_config(44100, 48000, ch, 256, 16, drbamd.PUSH, drbamd.GOOD,
+                                arithmetic=drbamd.FAST, streams=streams)
+    batch = drbamd.Batch(config)
+    cap = batch.query([frames] * streams)[0] + 4096
+    src = torch.rand((streams, ch, frames + 4096), device="cuda") * 2 - 1
+    dst = torch.zeros((streams, ch, cap), device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    counters = (ctypes.c_ulonglong * 96)()
+    drbamd.lib.drb_amd_debug_counters.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+    for step in range(3):
+        batch.process_dense(src.data_ptr(), ch * (frames + 4096), frames + 4096, dst.data_ptr(), ch * cap, cap,
+                            frames, cap, stream=stream)
+        batch.synchronize(stream)
+        drbamd.check(drbamd.lib.drb_amd_debug_counters(batch.handle, counters, 96))
+    tiles = streams * ch * 19
+    for wave in range(6):
+        names = LOADER if wave == 5 else FILTER
+        row = [counters[16 * wave + p] for p in range(len(names))]
+        print("wave %d  %6.0f cycles per tile:  " % (wave, sum(row) / tiles)
+              + "  ".join("%s %.0f" % (names[p], row[p] / tiles) for p in range(len(names))))
+
+
+if __name__ == "__main__":
+    main()
