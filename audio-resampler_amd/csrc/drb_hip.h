@@ -89,8 +89,8 @@ typedef struct Drb_Fast_Chain
     int waves;                              /* waves per workgroup: 4 or 5, whichever deals the row blocks out more evenly */
     float column_drift;                     /* sub-sample position of segment c minus segment c - 1 (0: too small to matter) */
     int types_per_wave;                     /* row-block types one wave keeps coefficients for */
-    int plane_stride, plane_rows;           /* kind 3, planar float32: floats between segments of a source plane in LDS
-                                               ([segment][row], filled by global-to-LDS loads), and floats loaded per segment */
+    int plane_stride, plane_rows;           /* kind 3, planar float32: floats of a source plane in LDS (a straight copy of
+                                               the source, whole 256-frame loads), and rows one segment needs of it */
     int lds_floats;
     int tile_frames;                        /* target frames per tile = 15 * seg_y    */
     long long source_delta, target_delta;

@@ -1997,7 +1997,7 @@ extern "C" int drb_hip_launch_collapse_build
 
     if (status != hipSuccess) return status;
 
-    drb_collapse_build_kernel<<<dim3(static_cast<unsigned>(job_count), static_cast<unsigned>(chain->blocks), 2), dim3(256), dynamic, static_cast<hipStream_t>(stream)>>>
+    drb_collapse_build_kernel<<<dim3(static_cast<unsigned>(job_count), static_cast<unsigned>(chain->blocks), 2), dim3(1024), dynamic, static_cast<hipStream_t>(stream)>>>
     (
         *chain, jobs, sets, collapse_set_words(chain->blocks, chain->ksteps), fault_flag
     );

@@ -1015,16 +1015,15 @@ int drb_plan_collapse_geometry (Drb_Fast_Chain * chain, int lds_budget_bytes)
     c.lds_floats = (c.seg_x + c.look_x + 8) * 16;
     c.tile_frames = 16 * c.seg_y;
 
-    /* Planar float32 sources go to LDS without passing through registers, four
-     * planes going round, as [segment][row]: rows of one segment are consecutive (a
-     * wave-wide load lands 64 x 16 consecutive bytes), segments 8 .. 15 two rows
-     * later than their place so that the 64 lanes of an operand read (rows quad,
-     * segments 0 .. 15) meet 32 different banks in either half. */
-    c.plane_rows = (c.seg_x + c.look_x + 8 + 2 + 3) / 4 * 4;
-    c.plane_stride = c.plane_rows;
-    while (c.plane_stride % 32 != 4) c.plane_stride++;
+    /* Planar float32 sources: a plane in LDS is a straight copy of the stretch of
+     * the source that the 16 segments of a tile need, from a 128-byte line on
+     * (up to 31 frames in front), in 12 or 16 wave-wide loads of 256 frames
+     * (the kernel images there are); three planes take turns.  plane_rows: rows
+     * of one segment; plane_stride: floats of a plane. */
+    c.plane_rows = (c.seg_x + c.look_x + 8 + 3) / 4 * 4;
+    c.plane_stride = 15 * c.seg_x + c.plane_rows + 31 <= 12 * 256 ? 12 * 256 : 16 * 256;
 
-    if (4 * 16 * c.plane_stride > c.lds_floats) c.lds_floats = 4 * 16 * c.plane_stride;
+    if (15 * c.seg_x + c.plane_rows + 31 <= c.plane_stride && 3 * c.plane_stride > c.lds_floats) c.lds_floats = 3 * c.plane_stride;
 
     if (c.lds_floats * 4 > lds_budget_bytes) return 0;
 
