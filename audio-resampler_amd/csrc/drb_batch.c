@@ -308,14 +308,18 @@ static int build_launches (DrbAmd_Batch_Config const * config, Drb_Plan const * 
 
         if (!launch->fast.usable || !drb_hip_fast_kernel_exists(&launch->fast)) return 0;
 
-        /* [up] sinc [down] as one filter where that form applies: an experiment,
-         * asked for with DRB_AMD_FAST_COLLAPSED=1 (the three stages are the faster
-         * kernel so far) */
-        if (launch->has_sinc && getenv("DRB_AMD_FAST_COLLAPSED") && atoi(getenv("DRB_AMD_FAST_COLLAPSED")))
+        /* [up] sinc [down] as one filter where that form applies and is the faster
+         * kernel (DRB_AMD_FAST_COLLAPSED, a diagnostic: 0 keeps the three stages
+         * everywhere, 1 collapses wherever a kernel image exists) */
+        char const * const wish = getenv("DRB_AMD_FAST_COLLAPSED");
+        int const forced = wish && atoi(wish) > 0, forbidden = wish && atoi(wish) == 0;
+
+        if (launch->has_sinc && !forbidden)
         {
             Drb_Fast_Chain collapsed = launch->fast;
 
-            if (drb_plan_collapse_geometry(&collapsed, fast_lds_budget) && drb_hip_fast_kernel_exists(&collapsed))
+            if (drb_plan_collapse_geometry(&collapsed, fast_lds_budget) && drb_hip_fast_kernel_exists(&collapsed)
+                && (forced || drb_hip_collapsed_preferred(&collapsed)))
             {
                 launch->fast = collapsed;
             }

@@ -178,6 +178,10 @@ int drb_hip_launch_fast
  * (collapse_set_words(chain) 32-bit words each), then the filter itself:
  * spots[stream * max_stretches + stretch]. */
 long long drb_hip_collapse_set_words (Drb_Fast_Chain const * chain);
+/* 1 where the collapsed kernel of this chain beats the staged one (measured:
+ * planar float32 buffers, and few enough steps that its coefficients stay in
+ * registers) */
+int drb_hip_collapsed_preferred (Drb_Fast_Chain const * chain);
 int drb_hip_launch_collapse_build
     (
         Drb_Fast_Chain const * chain, Drb_Collapse_Job const * jobs, int job_count,

@@ -1973,6 +1973,12 @@ extern "C" int drb_hip_fast_kernel_exists (Drb_Fast_Chain const * chain)
                             : pick_kernel(chain) != nullptr;
 }
 
+extern "C" int drb_hip_collapsed_preferred (Drb_Fast_Chain const * chain)
+{
+    // (31 steps and more spill coefficients to scratch memory)
+    return chain->kind == 3 && collapsed_is_plain(chain) && pick_collapsed_plain(chain) != nullptr && chain->ksteps <= 29;
+}
+
 extern "C" long long drb_hip_collapse_set_words (Drb_Fast_Chain const * chain)
 {
     return collapse_set_words(chain->blocks, chain->ksteps);
