@@ -245,6 +245,8 @@ def main():
     if fast:
         kinds = set(kind for kind in info.stage_kind[:info.stage_count] if kind != 4)
         kernel = "drb_fast_kernel" if 3 in kinds else "drb_decimate_kernel" if kinds == {2} else "drb_interpolate_kernel"
+        if info.fast_collapsed:
+            kernel = "drb_collapsed_plain_kernel" if (sample, layout) == ("f32", "planar") else "drb_collapsed_kernel"
         if info.fast_launches > 1:
             kernel += " + %d half-band launches" % (info.fast_launches - 1)
     roofline.update({"traffic": traffic, "kernel": kernel,
@@ -256,7 +258,7 @@ def main():
         # the matrix-core kernel merges upstream's two (or four) dot products per
         # output into one and pads its banded products: what it really issues
         issued = info.fast_issued_flops_per_output_sample
-        if info.fast_launches == 1 and 3 in kinds and streams * ch >= 2048:
+        if info.fast_launches == 1 and 3 in kinds and streams * ch >= 2048 and not info.fast_collapsed:
             # one workgroup then walks over all tiles of a stream and only its
             # first tile spends a segment on warming up: 16 useful segments per
             # tile instead of the 15 the figure is stated for

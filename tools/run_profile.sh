@@ -1,0 +1,30 @@
+#!/bin/bash
+# One GPU call: parity tests, the default bench line, a rocprofv3 kernel trace of
+# the same command and the PMC passes for HBM traffic and issue counters.
+# usage: tools/run_profile.sh [tag]   (results under gpurun_out/<tag>/)
+set -o pipefail
+TAG=${1:-prof}
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd $ROOT
+if [ -z "$SKIP_TESTS" ]; then
+timeout -k 10 900 python3 -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > $OUT/pytest_gpu.log 2>&1 || { tail -30 $OUT/pytest_gpu.log; exit 1; }
+tail -2 $OUT/pytest_gpu.log
+fi
+timeout -k 10 300 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || { tail -20 $OUT/bench.err; exit 1; }
+cat $OUT/bench.json
+export TMPDIR=/tmp
+BENCH="python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-host-fed"
+cd /tmp
+timeout -s KILL 180 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- $BENCH > $OUT/trace/bench.log 2> $OUT/trace.err || { tail -20 $OUT/trace.err; exit 1; }
+for pass in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" \
+            "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_WAVES SQ_INSTS_BRANCH" \
+            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT"
+do
+    name=$(echo $pass | cut -d' ' -f1)
+    timeout -s KILL 120 rocprofv3 --pmc $pass -d $OUT/pmc_$name -o pmc --output-format csv -- $BENCH > $OUT/pmc_$name.log 2>&1 || { tail -20 $OUT/pmc_$name.log; exit 1; }
+done
+cd $ROOT
+for d in $OUT/pmc_*/; do python3 tools/pmc_summary.py $d drb_; done > $OUT/pmc_summary.txt
+cat $OUT/pmc_summary.txt
