@@ -2030,7 +2030,9 @@ extern "C" int drb_hip_launch_collapsed
 
     if ((!kernel && !plain_kernel) || max_stretches < 1 || (plain && !zeros)) return hipErrorInvalidValue;
 
-    size_t const dynamic = static_cast<size_t>(chain->lds_floats) * sizeof(float);
+    // (planar float32: every filtering wave parks its coefficients' slopes behind the planes)
+    size_t const dynamic = static_cast<size_t>(chain->lds_floats) * sizeof(float)
+        + (plain ? static_cast<size_t>(chain->waves) * chain->types_per_wave * ((chain->ksteps + 1) / 2) * 64 * sizeof(unsigned) : 0);
 
     if (dynamic > 48 * 1024)
     {

@@ -43,5 +43,10 @@ def main():
               + "  ".join("%s %.0f" % (names[p], row[p] / tiles) for p in range(len(names))))
 
 
+    if counters[9]:
+        life, real = counters[8] / (streams * ch), counters[9] / (streams * ch)
+        print("workgroup lifetime %.0f cycles = %.2f us: shader clock %.2f GHz" % (life, real / 100.0, life / real * 0.1))
+
+
 if __name__ == "__main__":
     main()
