@@ -98,6 +98,22 @@ struct DrbAmd_Batch
     int kernel_timed;
 };
 
+/* ---- where the host's time goes (DRB_AMD_HOST_PROFILE=1 prints at destroy) ---- */
+
+#include <time.h>
+
+static double host_spent [6];
+static long host_steps;
+
+static double host_now (void)
+{
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)t.tv_sec * 1e6 + (double)t.tv_nsec * 1e-3;
+}
+
+#define HOST_MARK(section) do { double const now_ = host_now(); host_spent[section] += now_ - host_mark; host_mark = now_; } while (0)
+
 /* ---- errors ---------------------------------------------------------------- */
 
 static _Thread_local char last_error [256];
@@ -636,6 +652,12 @@ void drb_amd_batch_destroy (DrbAmd_Batch * batch)
 {
     if (!batch) return;
 
+    if (getenv("DRB_AMD_HOST_PROFILE") && host_steps > 0)
+    {
+        fprintf(stderr, "host us per step: frame arithmetic %.1f, descriptors %.1f, coefficient jobs + uploads %.1f, launches %.1f (%ld steps)\n",
+                host_spent[0] / host_steps, host_spent[1] / host_steps, host_spent[2] / host_steps, host_spent[3] / host_steps, host_steps);
+    }
+
     drb_hip_set_device(batch->device);
     release(batch);
 }
@@ -892,6 +914,7 @@ DrbAmd_Status drb_amd_batch_process
     int const n = batch->config.stream_count;
     int const pull = batch->plan.direction == 1;
     int most_target = 0, code;
+    double host_mark = host_now();
 
     /* phase 1: frame arithmetic on a copy of the state, so that a rejected
      * call leaves the batch untouched */
@@ -911,6 +934,8 @@ DrbAmd_Status drb_amd_batch_process
 
         if (step->target_frames > most_target) most_target = step->target_frames;
     }
+
+    HOST_MARK(0);
 
     if ((code = drb_hip_set_device(batch->device)) != 0) return fail_hip("hipSetDevice", code);
 
@@ -1009,6 +1034,8 @@ DrbAmd_Status drb_amd_batch_process
 
     int collapse_stretches = 1, collapse_job_count = 0;
 
+    HOST_MARK(1);
+
     for (int l = 0; l < launches; l++)
     {
         if (fast && batch->launches[l].fast.kind == 3)
@@ -1019,6 +1046,8 @@ DrbAmd_Status drb_amd_batch_process
             if (status != drb_amd_ok) return status;
         }
     }
+
+    HOST_MARK(2);
 
     code = drb_hip_upload_async(batch->calls_device, calls, (size_t)n * launches * sizeof(Drb_Device_Call), hip_stream);
 
@@ -1105,6 +1134,9 @@ DrbAmd_Status drb_amd_batch_process
     if (!code) code = drb_hip_event_record(batch->slot_done[slot], hip_stream);
 
     if (code) return fail_hip("launch", code);
+
+    HOST_MARK(3);
+    host_steps++;
 
     batch->slot_pending[slot] = 1;
     batch->slot = (slot + 1) % ring_slots;

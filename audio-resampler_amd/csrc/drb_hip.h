@@ -179,8 +179,8 @@ int drb_hip_launch_fast
  * spots[stream * max_stretches + stretch]. */
 long long drb_hip_collapse_set_words (Drb_Fast_Chain const * chain);
 /* 1 where the collapsed kernel of this chain beats the staged one (measured:
- * planar float32 buffers, and few enough steps that its coefficients stay in
- * registers) */
+ * planar float32 buffers, a tile's source in 12 wave-wide loads, and an odd
+ * segment length, which keeps its operand reads free of LDS bank conflicts) */
 int drb_hip_collapsed_preferred (Drb_Fast_Chain const * chain);
 int drb_hip_launch_collapse_build
     (

@@ -1975,8 +1975,14 @@ extern "C" int drb_hip_fast_kernel_exists (Drb_Fast_Chain const * chain)
 
 extern "C" int drb_hip_collapsed_preferred (Drb_Fast_Chain const * chain)
 {
-    // (31 steps and more spill coefficients to scratch memory)
-    return chain->kind == 3 && collapsed_is_plain(chain) && pick_collapsed_plain(chain) != nullptr && chain->ksteps <= 29;
+    // Measured: 44.1 -> 48 kHz good 0.38 against the staged kernel's 0.56 ms, best
+    // 0.45 against 0.60; but 48 -> 44.1 kHz 0.85 against 0.59.  There a segment
+    // is 160 source frames long, and since a plane is a straight copy of the
+    // source the 16 segments of an operand read lie 160 floats apart: all in one
+    // LDS bank.  An odd segment length spreads them over 16 banks.  (With 16
+    // loads per tile the workgroup also runs one to a CU instead of two.)
+    return chain->kind == 3 && collapsed_is_plain(chain) && pick_collapsed_plain(chain) != nullptr
+        && chain->plane_stride == 12 * 256 && (chain->seg_x & 1);
 }
 
 extern "C" long long drb_hip_collapse_set_words (Drb_Fast_Chain const * chain)

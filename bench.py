@@ -198,6 +198,7 @@ def main():
     out_frames = 0
     for _ in range(args.steps):
         out_frames += step()
+    host_elapsed = time.perf_counter() - start   # the host's share: descriptors, planning, launches
     barrier()
     elapsed = time.perf_counter() - start
     batch.synchronize(stream)
@@ -272,6 +273,7 @@ def main():
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "host_ms_per_step": round(host_elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic white noise, uniform [-1, 1)",
             "config": {"workload": "%d x %d-ch %s %d->%d Hz per GPU, quality %s, %s, %s layout, %.2f s per step, %s arithmetic"

@@ -8,5 +8,5 @@ for w in ${WORKLOADS:-headline}; do
 timeout -k 10 200 python3 bench.py --workload $w --steps 20 --warmup 3 --no-host-fed --no-cpu-baseline > gpurun_out/bench_quick.json 2> gpurun_out/bench_quick.err || { tail gpurun_out/bench_quick.err; exit 1; }
 python3 -c '
 import json,sys
-d=json.load(open("gpurun_out/bench_quick.json")); r=d["roofline"]; print(sys.argv[1], "ms/step", d["ms_per_step"], "kernel_ms", r["kernel_ms"], r["bound"], r["frac"], r["kernel"])' $w
+d=json.load(open("gpurun_out/bench_quick.json")); r=d["roofline"]; print(sys.argv[1], "ms/step", d["ms_per_step"], "host", d["host_ms_per_step"], "kernel_ms", r["kernel_ms"], r["bound"], r["frac"], r["kernel"])' $w
 done
