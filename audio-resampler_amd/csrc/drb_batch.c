@@ -334,7 +334,8 @@ static int build_launches (DrbAmd_Batch_Config const * config, Drb_Plan const * 
         {
             Drb_Fast_Chain collapsed = launch->fast;
 
-            if (drb_plan_collapse_geometry(&collapsed, fast_lds_budget) && drb_hip_fast_kernel_exists(&collapsed)
+            if (drb_plan_collapse_geometry(&collapsed, fast_lds_budget) && (drb_hip_collapsed_shape(&collapsed), 1)
+                && drb_hip_fast_kernel_exists(&collapsed)
                 && (forced || drb_hip_collapsed_preferred(&collapsed)))
             {
                 launch->fast = collapsed;

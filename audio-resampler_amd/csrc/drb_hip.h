@@ -182,6 +182,8 @@ long long drb_hip_collapse_set_words (Drb_Fast_Chain const * chain);
  * planar float32 buffers, a tile's source in 12 wave-wide loads, and an odd
  * segment length, which keeps its operand reads free of LDS bank conflicts) */
 int drb_hip_collapsed_preferred (Drb_Fast_Chain const * chain);
+/* settles how many waves filter (the kernel images that exist decide) */
+void drb_hip_collapsed_shape (Drb_Fast_Chain * chain);
 int drb_hip_launch_collapse_build
     (
         Drb_Fast_Chain const * chain, Drb_Collapse_Job const * jobs, int job_count,
