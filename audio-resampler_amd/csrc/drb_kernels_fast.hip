@@ -1997,7 +1997,7 @@ extern "C" int drb_hip_collapsed_preferred (Drb_Fast_Chain const * chain)
     // LDS bank.  An odd segment length spreads them over 16 banks.  (With 16
     // loads per tile the workgroup also runs one to a CU instead of two.)
     return chain->kind == 3 && collapsed_is_plain(chain) && pick_collapsed_plain(chain) != nullptr
-        && chain->plane_stride == 12 * 256 && (chain->seg_x & 1);
+        && chain->plane_stride <= 12 * 256 && (chain->seg_x & 1);
 }
 
 extern "C" long long drb_hip_collapse_set_words (Drb_Fast_Chain const * chain)

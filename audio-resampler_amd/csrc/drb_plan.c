@@ -1017,11 +1017,12 @@ int drb_plan_collapse_geometry (Drb_Fast_Chain * chain, int lds_budget_bytes)
 
     /* Planar float32 sources: a plane in LDS is a straight copy of the stretch of
      * the source that the 16 segments of a tile need, from a 128-byte line on
-     * (up to 31 frames in front), in 12 or 16 wave-wide loads of 256 frames
+     * (up to 31 frames in front), in 10, 12 or 16 wave-wide loads of 256 frames
      * (the kernel images there are); three planes take turns.  plane_rows: rows
      * of one segment; plane_stride: floats of a plane. */
     c.plane_rows = (c.seg_x + c.look_x + 8 + 3) / 4 * 4;
-    c.plane_stride = 15 * c.seg_x + c.plane_rows + 31 <= 12 * 256 ? 12 * 256 : 16 * 256;
+    c.plane_stride = 15 * c.seg_x + c.plane_rows + 31 <= 10 * 256 ? 10 * 256
+                   : 15 * c.seg_x + c.plane_rows + 31 <= 12 * 256 ? 12 * 256 : 16 * 256;
 
     if (15 * c.seg_x + c.plane_rows + 31 <= c.plane_stride && 3 * c.plane_stride > c.lds_floats) c.lds_floats = 3 * c.plane_stride;
 

@@ -3,7 +3,10 @@
 
 One step = every stream of the batch pushes `--seconds` of synthetic white
 noise through the cascade (state carried from step to step), with the source
-and target buffers already resident in HBM.  N > 1 runs one process per GPU
+and target buffers already resident in HBM.  The default, 10 s, is the stream
+length of the workload definition, converted in one call per step; with
+`--seconds 1` the per-step costs (coefficient sets, descriptor uploads, the
+first and last tiles of every stream) weigh ten times as much.  N > 1 runs one process per GPU
 (torch.distributed over RCCL is used for the barrier and the max-over-ranks
 only; streams are independent, there is no collective on the data path), each
 rank owning its own `--streams` streams: weak scaling.
@@ -122,7 +125,8 @@ def main():
     parser.add_argument("--warmup", type=int, default=3)
     parser.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
     parser.add_argument("--streams", type=int, default=0, help="streams per GPU (0 = workload default)")
-    parser.add_argument("--seconds", type=float, default=1.0, help="audio seconds per stream per step")
+    parser.add_argument("--seconds", type=float, default=10.0,
+                        help="audio seconds per stream per step (10 s = a whole stream of the survey's workload in one call)")
     parser.add_argument("--arithmetic", default="fast", choices=["exact", "fast"])
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--no-host-fed", action="store_true", help="skip the PCIe-inclusive side measurement")
