@@ -131,3 +131,27 @@ def test_fast_mode_integer_outputs_within_one_lsb(sample, layout):
         # float32 carries 24 bits: one LSB of the float result is up to 128 int32 steps here;
         # the +-1 LSB bound on int32 needs the exact mode (see test_gpu_parity)
         assert diff.max() <= 2048
+
+
+def test_fast_mode_whole_ten_second_stream_per_step():
+    """The benchmark's step: a whole 10 s stream in one call (188 tiles per
+    channel, 24 stretches of coefficient sets), with the kernels the library
+    picks by default; the second stream takes the same samples in two calls of
+    odd lengths, so that its phases, and with them its coefficient sets, differ
+    from the first stream's in the second call."""
+    ch, frames = 2, 10 * 44100
+    x = support.white_noise(ch, frames, 77)
+    status, plan = support.oracle_plan(44100, 48000, ch, 256, 16, PUSH, support.GOOD)
+    assert status == 1
+    want = support.oracle_push(plan, x)
+    config = drbamd.make_config(44100, 48000, ch, 256, 16, PUSH, support.GOOD, arithmetic=drbamd.FAST, streams=2)
+    assert drbamd.plan_info(config).fast_collapsed == 1
+    runner = gpu_support.StreamRunner(config, [x, x])
+    schedules = [gpu_support.chunk_schedule(frames, p) for p in ([frames], [12345, frames - 12345])]
+    for i in range(max(len(s) for s in schedules)):
+        runner.step([s[i] if i < len(s) else 0 for s in schedules])
+    for s in range(2):
+        got = runner.result(s)
+        assert got.shape == want.shape
+        assert_close(got, want, "stream %d" % s)
+    runner.close()
