@@ -1139,7 +1139,10 @@ __device__ __forceinline__ void store_tile
 // word 0), and chain.ablate switches stages off.  Never compiled into the
 // library that ships.
 #ifdef DRB_FAST_STAMPS
-#  define STAMP(phase) do { long long const now_ = __builtin_readcyclecounter(); spent[phase] += now_ - mark; mark = now_; } while (0)
+// (the counter is a scalar-memory read: left pending it turns every later LDS
+// wait into a wait for everything, so it is waited for on the spot)
+#  define STAMP(phase) do { long long const now_ = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory"); \
+                            spent[phase] += now_ - mark; mark = now_; } while (0)
 #  define ABLATED(bit) (chain.ablate & (bit))
 #else
 #  define STAMP(phase) do { } while (0)

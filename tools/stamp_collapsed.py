@@ -15,12 +15,12 @@ import torch
 
 import drbamd
 
-FILTER = ["top", "barrier", "lds", "multiply+write"]
+FILTER = ["drift update", "barrier", "lds", "multiply+write", "bookkeeping+reload"]
 LOADER = ["issue", "wait", "barrier"]
 
 
 def main():
-    streams, ch, frames = 1024, 2, 44032
+    streams, ch, frames = 1024, 2, int(os.environ.get("STAMP_FRAMES", "44032"))
     config = drbamd.make_config(44100, 48000, ch, 256, 16, drbamd.PUSH, drbamd.GOOD,
                                 arithmetic=drbamd.FAST, streams=streams)
     batch = drbamd.Batch(config)
@@ -35,7 +35,7 @@ def main():
                             frames, cap, stream=stream)
         batch.synchronize(stream)
         drbamd.check(drbamd.lib.drb_amd_debug_counters(batch.handle, counters, 96))
-    tiles = streams * ch * 19
+    tiles = streams * ch * ((frames * 160 // 147 + 2559) // 2560)
     for wave in range(6):
         names = LOADER if wave == 5 else FILTER
         row = [counters[16 * wave + p] for p in range(len(names))]
@@ -43,6 +43,8 @@ def main():
               + "  ".join("%s %.0f" % (names[p], row[p] / tiles) for p in range(len(names))))
 
 
+    for wave in range(5):
+        print("wave %d ran on SIMD 0/1/2/3 in %s workgroups" % (wave, [counters[16 * wave + 10 + i] for i in range(4)]))
     if counters[9]:
         life, real = counters[8] / (streams * ch), counters[9] / (streams * ch)
         print("workgroup lifetime %.0f cycles = %.2f us: shader clock %.2f GHz" % (life, real / 100.0, life / real * 0.1))
