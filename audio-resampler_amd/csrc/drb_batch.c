@@ -334,11 +334,23 @@ static int build_launches (DrbAmd_Batch_Config const * config, Drb_Plan const * 
         {
             Drb_Fast_Chain collapsed = launch->fast;
 
-            if (drb_plan_collapse_geometry(&collapsed, fast_lds_budget) && (drb_hip_collapsed_shape(&collapsed), 1)
-                && drb_hip_fast_kernel_exists(&collapsed)
-                && (forced || drb_hip_collapsed_preferred(&collapsed)))
+            if (drb_plan_collapse_geometry(&collapsed, fast_lds_budget))
             {
-                launch->fast = collapsed;
+                /* the same filter on the half-precision matrix instruction where
+                 * that kernel fits (DRB_AMD_FAST_SPLIT=0, a diagnostic, keeps it off) */
+                Drb_Fast_Chain split = collapsed;
+                char const * const split_wish = getenv("DRB_AMD_FAST_SPLIT");
+
+                if (!(split_wish && atoi(split_wish) == 0) && drb_plan_split_geometry(&split, fast_lds_budget)
+                    && drb_hip_fast_kernel_exists(&split))
+                {
+                    launch->fast = split;
+                }
+                else if ((drb_hip_collapsed_shape(&collapsed), 1) && drb_hip_fast_kernel_exists(&collapsed)
+                         && (forced || drb_hip_collapsed_preferred(&collapsed)))
+                {
+                    launch->fast = collapsed;
+                }
             }
         }
     }
@@ -361,6 +373,13 @@ static double issued_flops (Fast_Launch const * launches, int count)
         if (fast->kind == 3)
         {
             total += 2048.0 * (double)fast->blocks * fast->ksteps / (double)fast->tile_frames * launches[i].rate_ratio;
+            continue;
+        }
+
+        if (fast->kind == 4)
+        {
+            /* four 16 x 16 x 32 products of 16384 flop per row block and step */
+            total += 4.0 * 16384.0 * (double)fast->blocks * fast->chunks / (double)fast->tile_frames * launches[i].rate_ratio;
             continue;
         }
 
@@ -419,7 +438,7 @@ DrbAmd_Status drb_amd_plan_info (DrbAmd_Batch_Config const * config, DrbAmd_Plan
     info->fast_tile_frames = count > 0 ? launches[count - 1].fast.tile_frames : 0;
     info->fast_issued_flops_per_output_sample = issued_flops(launches, count);
 
-    for (int i = 0; i < count; i++) if (launches[i].fast.kind == 3) info->fast_collapsed = 1;
+    for (int i = 0; i < count; i++) if (launches[i].fast.kind >= 3) info->fast_collapsed = launches[i].fast.kind - 2;
 
     free(launches);
 
@@ -770,7 +789,8 @@ static DrbAmd_Status collapse_prepare
 {
     Drb_Fast_Chain const * const fast = &launch->fast;
     int const n = batch->config.stream_count;
-    int const wanted = fast->rebuild_tiles > 0 ? fast->rebuild_tiles : drb_collapse_rebuild_tiles;
+    int const wanted = fast->rebuild_tiles > 0 ? fast->rebuild_tiles
+                     : fast->kind == 4 ? drb_split_stretch_tiles : drb_collapse_rebuild_tiles;
     int max_stretches = 1, code;
     size_t total = 0;
 
@@ -1039,7 +1059,7 @@ DrbAmd_Status drb_amd_batch_process
 
     for (int l = 0; l < launches; l++)
     {
-        if (fast && batch->launches[l].fast.kind == 3)
+        if (fast && batch->launches[l].fast.kind >= 3)
         {
             DrbAmd_Status const status = collapse_prepare(batch, &batch->launches[l], calls + (size_t)l * n, slot, hip_stream,
                                                           &collapse_stretches, &collapse_job_count);
@@ -1058,7 +1078,7 @@ DrbAmd_Status drb_amd_batch_process
      * was measured far slower: every cross-stream wait cost most of a millisecond) */
     for (int l = 0; l < launches && !code; l++)
     {
-        if (fast && batch->launches[l].fast.kind == 3)
+        if (fast && batch->launches[l].fast.kind >= 3)
         {
             code = drb_hip_launch_collapse_build(&batch->launches[l].fast, batch->collapse_jobs, collapse_job_count,
                                                  batch->collapse_sets, batch->fault_device, hip_stream);
@@ -1077,7 +1097,7 @@ DrbAmd_Status drb_amd_batch_process
             long long const target_stride = l == launches - 1 ? target_channel_stride : launch->output_frames;
             int const fast_tile = launch->fast.tile_frames;
 
-            if (launch->fast.kind == 3)
+            if (launch->fast.kind >= 3)
             {
                 code = drb_hip_launch_collapsed
                 (

@@ -85,12 +85,15 @@ typedef struct Drb_Fast_Chain
     int off_bank;                           /* sinc bank while coefficients are rebuilt: shares the planes of d where a down-sampler exists */
     int off_taps;                           /* half-band taps, zero-padded: up, then down */
     int kind;                               /* 0: [up] sinc [down]; 1: one half-band decimator on its own; 2: one interpolator;
-                                               3: [up] sinc [down] collapsed into one time-varying filter (see Drb_Collapse_Job) */
+                                               3: [up] sinc [down] collapsed into one time-varying filter (see Drb_Collapse_Job);
+                                               4: the same filter with every float32 carried as two halves (see below) */
     int waves;                              /* waves per workgroup: 4 or 5, whichever deals the row blocks out more evenly */
     float column_drift;                     /* sub-sample position of segment c minus segment c - 1 (0: too small to matter) */
     int types_per_wave;                     /* row-block types one wave keeps coefficients for */
     int plane_stride, plane_rows;           /* kind 3, planar float32: floats of a source plane in LDS (a straight copy of
                                                the source, whole 256-frame loads), and rows one segment needs of it */
+    int window;                             /* kinds 3, 4: source frames a row block's 16 target frames depend on, at most */
+    int chunks;                             /* kind 4: 32-frame steps of a row block's window (3 or 4)                      */
     int lds_floats;
     int tile_frames;                        /* target frames per tile = 15 * seg_y    */
     long long source_delta, target_delta;
@@ -108,6 +111,19 @@ Drb_Fast_Chain;
  * middle of a stretch of `rebuild_tiles` tiles, and every tile of the stretch
  * uses it, corrected to first order for the drift since the anchor. */
 enum { drb_collapse_max_blocks = 12, drb_collapse_rebuild_tiles = 8 /* tiles per stretch */ };
+
+/* Split chains (kind 4): the collapsed filter on v_mfma_f32_16x16x32_f16, which
+ * runs at 16 times the rate of the float32 matrix instruction.  Every float32
+ * value v, source sample or coefficient, travels as two halves h = half(v) and
+ * l = half((v - h) * 2048), and a product c x is accumulated in float32 as
+ * ch xh + (ch xl + cl xh) / 2048; the dropped term cl xl is below 2^-22 |c x|.
+ * A window is `chunks` steps of 32 source frames; a workgroup is one wave per
+ * row block plus four that load.  The drift of the fixed-point phase is not
+ * folded into the coefficients: a fourth product with the coefficients'
+ * derivatives is scaled per tile AND per segment by the distance from the
+ * stretch's anchor, so a set serves a stretch of drb_split_stretch_tiles tiles
+ * and every segment gets its own phase. */
+enum { drb_split_max_blocks = 10, drb_split_stretch_tiles = 64, drb_split_loaders = 4, drb_split_planes = 3 };
 
 typedef struct Drb_Collapse_Job
 {
@@ -182,6 +198,8 @@ long long drb_hip_collapse_set_words (Drb_Fast_Chain const * chain);
  * planar float32 buffers, a tile's source in 12 wave-wide loads, and an odd
  * segment length, which keeps its operand reads free of LDS bank conflicts) */
 int drb_hip_collapsed_preferred (Drb_Fast_Chain const * chain);
+/* 32-bit words of one coefficient set of a kind 4 chain */
+long long drb_hip_split_set_words (Drb_Fast_Chain const * chain);
 /* settles how many waves filter (the kernel images that exist decide) */
 void drb_hip_collapsed_shape (Drb_Fast_Chain * chain);
 int drb_hip_launch_collapse_build

@@ -1873,6 +1873,7 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_interpolate_kernel
 }
 
 #include "drb_collapsed.inc"
+#include "drb_split.inc"
 
 typedef void Fast_Kernel
     (
@@ -1972,7 +1973,8 @@ Fast_Kernel * pick_kernel (Drb_Fast_Chain const * chain)
 
 extern "C" int drb_hip_fast_kernel_exists (Drb_Fast_Chain const * chain)
 {
-    return chain->kind == 3 ? (collapsed_is_plain(chain) ? pick_collapsed_plain(chain) != nullptr : pick_collapsed(chain) != nullptr)
+    return chain->kind == 4 ? pick_split(chain) != nullptr
+         : chain->kind == 3 ? (collapsed_is_plain(chain) ? pick_collapsed_plain(chain) != nullptr : pick_collapsed(chain) != nullptr)
                             : pick_kernel(chain) != nullptr;
 }
 
@@ -2005,7 +2007,7 @@ extern "C" int drb_hip_collapsed_preferred (Drb_Fast_Chain const * chain)
 
 extern "C" long long drb_hip_collapse_set_words (Drb_Fast_Chain const * chain)
 {
-    return collapse_set_words(chain->blocks, chain->ksteps);
+    return chain->kind == 4 ? split_set_words(chain->blocks, chain->chunks) : collapse_set_words(chain->blocks, chain->ksteps);
 }
 
 extern "C" int drb_hip_launch_collapse_build
@@ -2015,7 +2017,7 @@ extern "C" int drb_hip_launch_collapse_build
     )
 {
     if (job_count <= 0) return 0;
-    if (chain->kind != 3 || chain->blocks < 1 || chain->blocks > drb_collapse_max_blocks) return hipErrorInvalidValue;
+    if ((chain->kind != 3 && chain->kind != 4) || chain->blocks < 1 || chain->blocks > drb_collapse_max_blocks) return hipErrorInvalidValue;
 
     size_t const dynamic = static_cast<size_t>(kBuildOutputs) * (kBuildWide + 32) * sizeof(double);
 
@@ -2029,7 +2031,7 @@ extern "C" int drb_hip_launch_collapse_build
 
     drb_collapse_build_kernel<<<dim3(static_cast<unsigned>(job_count), static_cast<unsigned>(chain->blocks), 2), dim3(1024), dynamic, static_cast<hipStream_t>(stream)>>>
     (
-        *chain, jobs, sets, collapse_set_words(chain->blocks, chain->ksteps), fault_flag
+        *chain, jobs, sets, drb_hip_collapse_set_words(chain), fault_flag
     );
 
     return hipGetLastError();
@@ -2047,6 +2049,41 @@ extern "C" int drb_hip_launch_collapsed
     )
 {
     if (stream_count <= 0 || max_tiles <= 0) return 0;
+
+    if (chain->kind == 4)
+    {
+        Split_Kernel * const split = pick_split(chain);
+
+        if (!split || max_stretches < 1) return hipErrorInvalidValue;
+
+        size_t const bytes = static_cast<size_t>(chain->lds_floats) * sizeof(unsigned);
+
+        if (bytes > 48 * 1024)
+        {
+            hipError_t const status = hipFuncSetAttribute(reinterpret_cast<void const *>(split),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+
+            if (status != hipSuccess) return status;
+        }
+
+        // one workgroup fills a CU; a workgroup walks over the tiles of its stream
+        // and channel with a stride, a few workgroups per CU in all
+        long long const pairs = static_cast<long long>(stream_count) * chain->channels;
+        long long stride = (1024 + pairs - 1) / pairs;
+
+        if (chain->tile_stride > 0) stride = chain->tile_stride;
+        if (stride > max_tiles) stride = max_tiles;
+        if (stride < 1) stride = 1;
+        if (pairs * stride > 0x7fffffffLL) return hipErrorInvalidValue;
+
+        split<<<dim3(static_cast<unsigned>(pairs * stride)), dim3(static_cast<unsigned>(64 * (chain->blocks + kSplitLoaders))), bytes, static_cast<hipStream_t>(stream)>>>
+        (
+            *chain, calls, stream_count, static_cast<int>(stride), history,
+            source_channel_stride, target_channel_stride, jobs, spots, max_stretches, sets, fault_flag
+        );
+
+        return hipGetLastError();
+    }
 
     bool const plain = collapsed_is_plain(chain);
     Collapsed_Kernel * const kernel = plain ? nullptr : pick_collapsed(chain);

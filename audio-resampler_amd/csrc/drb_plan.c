@@ -1002,6 +1002,7 @@ int drb_plan_collapse_geometry (Drb_Fast_Chain * chain, int lds_budget_bytes)
     int const rows = c.has_up ? (int)(span_all >> 1) + c.up_taps : (int)span_all + 1;
 
     c.ksteps = (width + 3) / 4 | 1;   /* kernel images exist for odd counts */
+    c.window = width;
     c.look_x = (rows - c.seg_x + 3) / 4 * 4;
     if (c.look_x < 4) c.look_x = 4;
     c.look_u = c.look_d = 0;
@@ -1025,6 +1026,50 @@ int drb_plan_collapse_geometry (Drb_Fast_Chain * chain, int lds_budget_bytes)
                    : 15 * c.seg_x + c.plane_rows + 31 <= 12 * 256 ? 12 * 256 : 16 * 256;
 
     if (15 * c.seg_x + c.plane_rows + 31 <= c.plane_stride && 3 * c.plane_stride > c.lds_floats) c.lds_floats = 3 * c.plane_stride;
+
+    if (c.lds_floats * 4 > lds_budget_bytes) return 0;
+
+    *chain = c;
+
+    return 1;
+}
+
+/* The collapsed form on the half-precision matrix instruction (kind 4, see
+ * drb_hip.h): the same segments and row blocks; a window is 3 or 4 steps of 32
+ * source frames, one wave per row block. */
+int drb_plan_split_geometry (Drb_Fast_Chain * chain, int lds_budget_bytes)
+{
+    if (chain->kind != 3 || chain->window < 1) return 0;
+
+    Drb_Fast_Chain c = *chain;
+
+    c.chunks = (c.window + 31) / 32;
+
+    if (c.chunks < 3) c.chunks = 3;
+    if (c.chunks > 4 || c.blocks > drb_split_max_blocks) return 0;
+
+    /* Segments lie seg_x words apart in a plane, and the 16 columns of an operand
+     * read must fall into 16 different LDS banks: an odd distance does that. */
+    if (!(c.seg_x & 1)) return 0;
+
+    c.kind = 4;
+    c.ksteps = 8 * c.chunks;          /* a window is 4 * ksteps rows, as for kind 3 */
+    c.waves = c.blocks;
+    c.types_per_wave = 1;
+
+    /* a window may not start behind the row that leaves it whole inside the segment's rows */
+    while (c.seg_x + c.look_x + 8 - 4 * c.ksteps < 0) c.look_x += 4;
+
+    c.plane_rows = (c.seg_x + c.look_x + 8 + 3) / 4 * 4;
+
+    int const reach = 15 * c.seg_x + c.plane_rows + 31;
+
+    c.plane_stride = reach <= 10 * 256 ? 10 * 256 : reach <= 12 * 256 ? 12 * 256 : 0;
+
+    if (!c.plane_stride) return 0;
+
+    c.off_x = 0;
+    c.lds_floats = drb_split_planes * c.plane_stride;
 
     if (c.lds_floats * 4 > lds_budget_bytes) return 0;
 

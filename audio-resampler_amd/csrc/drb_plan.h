@@ -141,6 +141,11 @@ int drb_plan_fast_geometry (Drb_Plan const * plan, int lds_budget_bytes, struct 
  * alone where that form does not apply. */
 int drb_plan_collapse_geometry (struct Drb_Fast_Chain * chain, int lds_budget_bytes);
 
+/* Turns a collapsed geometry (kind 3) into the split form (kind 4: the same
+ * filter on the half-precision matrix instruction, see drb_hip.h); returns 0
+ * and leaves the chain alone where no kernel of that form fits. */
+int drb_plan_split_geometry (struct Drb_Fast_Chain * chain, int lds_budget_bytes);
+
 /* A stretch of a stream's step, whose anchor segment (seg_y target frames each,
  * counted from the step's first) is `anchor_segment`: what its coefficients
  * depend on (rest, parity) and the source frame they are counted from. */

@@ -145,7 +145,7 @@ def test_fast_mode_whole_ten_second_stream_per_step():
     assert status == 1
     want = support.oracle_push(plan, x)
     config = drbamd.make_config(44100, 48000, ch, 256, 16, PUSH, support.GOOD, arithmetic=drbamd.FAST, streams=2)
-    assert drbamd.plan_info(config).fast_collapsed == 1
+    assert drbamd.plan_info(config).fast_collapsed == 2   # the split form of the collapsed filter
     runner = gpu_support.StreamRunner(config, [x, x])
     schedules = [gpu_support.chunk_schedule(frames, p) for p in ([frames], [12345, frames - 12345])]
     for i in range(max(len(s) for s in schedules)):
