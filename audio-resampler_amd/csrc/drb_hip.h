@@ -118,12 +118,12 @@ enum { drb_collapse_max_blocks = 12, drb_collapse_rebuild_tiles = 8 /* tiles per
  * l = half((v - h) * 2048), and a product c x is accumulated in float32 as
  * ch xh + (ch xl + cl xh) / 2048; the dropped term cl xl is below 2^-22 |c x|.
  * A window is `chunks` steps of 32 source frames; a workgroup is one wave per
- * row block plus four that load.  The drift of the fixed-point phase is not
+ * row block plus six that load.  The drift of the fixed-point phase is not
  * folded into the coefficients: a fourth product with the coefficients'
  * derivatives is scaled per tile AND per segment by the distance from the
  * stretch's anchor, so a set serves a stretch of drb_split_stretch_tiles tiles
  * and every segment gets its own phase. */
-enum { drb_split_max_blocks = 10, drb_split_stretch_tiles = 64, drb_split_loaders = 4, drb_split_planes = 3 };
+enum { drb_split_max_blocks = 10, drb_split_stretch_tiles = 64, drb_split_loaders = 6, drb_split_planes = 3 };
 
 typedef struct Drb_Collapse_Job
 {

@@ -1069,7 +1069,7 @@ int drb_plan_split_geometry (Drb_Fast_Chain * chain, int lds_budget_bytes)
     if (!c.plane_stride) return 0;
 
     c.off_x = 0;
-    c.lds_floats = drb_split_planes * c.plane_stride;
+    c.lds_floats = drb_split_planes * c.plane_stride + 2 * 16 * c.seg_y;   /* planes, then two images of a tile's target frames */
 
     if (c.lds_floats * 4 > lds_budget_bytes) return 0;
 

@@ -16,6 +16,7 @@ timeout -k 10 300 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || { tail
 cat $OUT/bench.json
 export TMPDIR=/tmp
 BENCH="python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-host-fed"
+mkdir -p $OUT/trace
 cd /tmp
 timeout -s KILL 180 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- $BENCH > $OUT/trace/bench.log 2> $OUT/trace.err || { tail -20 $OUT/trace.err; exit 1; }
 for pass in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" \
