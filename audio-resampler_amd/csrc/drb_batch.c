@@ -233,6 +233,12 @@ enum { lds_budget = 56 * 1024, fast_lds_budget = 78 * 1024 };
 static int build_launches (DrbAmd_Batch_Config const * config, Drb_Plan const * plan, Fast_Launch * launches)
 {
     int sinc = -1, count = 0;
+
+    /* One step of a 32-bit sample is 2^-31: finer than float32 resolves anywhere
+     * above 2^-7 of full scale, so "within one step of upstream" means the same
+     * float32 bit for bit.  Only the exact kernels deliver that: fast arithmetic
+     * on int32 buffers runs them. */
+    if (config->sample_type == drb_amd_sample_i32) return 0;
     int first [max_launches], last [max_launches];
 
     for (int k = 0; k < plan->stage_count; k++) if (plan->stages[k].kind == drb_stage_sinc) sinc = k;

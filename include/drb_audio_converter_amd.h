@@ -175,8 +175,13 @@ typedef enum DrbAmd_Arithmetic
     /* every multiply and add rounded separately, taps in upstream order:
      * float results are bit-identical to the upstream scalar build */
     drb_amd_arithmetic_exact = 0,
-    /* fused multiply-add, free summation order: within 1e-5 relative /
-     * 1e-6 absolute of upstream for inputs in [-1, 1] */
+    /* Matrix-core kernels, free summation order.  float32 buffers: within
+     * 1e-6 + 1e-5 |y| of upstream's y for samples in [-1, 1] (the same relative
+     * bound for larger samples, up to +-65504: they travel as pairs of halves).
+     * int16 buffers: within one step of upstream's integer.  int32 buffers:
+     * one step of 2^-31 is finer than float32 resolves, so only upstream's own
+     * float32, bit for bit, is within it; such batches run the exact kernels
+     * whatever this field says (DrbAmd_Plan_Info.fast_path reads 0). */
     drb_amd_arithmetic_fast = 1
 }
 DrbAmd_Arithmetic;
@@ -290,7 +295,9 @@ extern DrbAmd_Status drb_amd_batch_process_host_dense
     );
 
 /* Waits for the work enqueued on `hip_stream` and reports any error the
- * kernels flagged since the batch was created (their index-range checks). */
+ * kernels flagged since the batch was created (the exact kernels check every
+ * index range they derive; the matrix-core kernels read silence where a
+ * window reaches behind the history the batch keeps, and flag nothing). */
 extern DrbAmd_Status drb_amd_batch_synchronize (DrbAmd_Batch * batch, void * hip_stream);
 
 /* Measurement hook: when enabled, every process call brackets its cascade

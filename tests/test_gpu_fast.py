@@ -59,7 +59,17 @@ def test_fast_mode_within_tolerance_of_golden(name):
         x = DATA["%s.%s.in" % (name, kind)]
         want = DATA["%s.%s.out" % (name, kind)]
         if kind == "ramp":
-            continue  # values up to 600: outside the [-1, 1] range the bound is stated for
+            # values up to 600, outside the [-1, 1] range the absolute floor is stated for:
+            # the relative bound alone, on the scale of the signal
+            scale = float(np.abs(want).max())
+            runner = gpu_support.StreamRunner(config_for(meta, streams=1), [x])
+            total = x.shape[1] if meta["direction"] == PUSH else want.shape[1]
+            runner.step([total])
+            got = runner.result(0)[:, :want.shape[1]].astype(np.float64)
+            runner.close()
+            assert np.abs(got - want).max() <= REL_TOL * scale, "%s.ramp: %.3g on a scale of %.3g" % (
+                name, np.abs(got - want).max(), scale)
+            continue
         total = x.shape[1] if meta["direction"] == PUSH else want.shape[1]
         schedules = [gpu_support.chunk_schedule(total, p) for p in ([total], [997, 1, 2048, 333])]
         steps = max(len(s) for s in schedules)
@@ -128,9 +138,11 @@ def test_fast_mode_integer_outputs_within_one_lsb(sample, layout):
     if sample == drbamd.I16:
         assert diff.max() <= 1
     else:
-        # float32 carries 24 bits: one LSB of the float result is up to 128 int32 steps here;
-        # the +-1 LSB bound on int32 needs the exact mode (see test_gpu_parity)
-        assert diff.max() <= 2048
+        # One step of 2^-31 is finer than float32 resolves: only upstream's own float32
+        # bit for bit is within it, so fast arithmetic on int32 buffers runs the exact
+        # kernels (the header says so) and the integers are identical.
+        assert drbamd.plan_info(config_for(meta, sample_type=sample, layout=layout)).fast_path == 0
+        assert diff.max() == 0
 
 
 def test_fast_mode_whole_ten_second_stream_per_step():
