@@ -23,9 +23,14 @@ enum { ring_slots = 4, max_step_frames = 1 << 24, fault_words = 128, host_slots 
 
 enum { max_launches = drb_max_stages };
 
+static size_t const collapse_set_bytes_limit = (size_t)1 << 30;   /* of coefficient sets per step */
+
 typedef struct Fast_Launch
 {
     Drb_Fast_Chain fast;              /* geometry of this launch                                  */
+    Drb_Fast_Chain staged;            /* where `fast` is a collapsed form: the three stages kept apart,
+                                         for steps with too many different phases for coefficient sets */
+    int has_staged;
     Drb_Device_Chain chain;           /* for the history kernel of launches behind the first      */
     int ups_before, downs_behind;     /* 2x stages of the plan in front of / behind this launch   */
     int halves;                       /* 1: a decimator on its own (target = source / 2)          */
@@ -95,7 +100,11 @@ struct DrbAmd_Batch
 
     int timing;                       /* bracket the cascade kernel with events */
     void * kernel_start, * kernel_stop;
+    void * step_start, * step_stop;   /* ... and everything a step runs on the device */
     int kernel_timed;
+
+    void * last_stream;               /* stream of the step enqueued last, and whether there was one */
+    int last_slot;
 };
 
 /* ---- where the host's time goes (DRB_AMD_HOST_PROFILE=1 prints at destroy) ---- */
@@ -133,6 +142,8 @@ static DrbAmd_Status fail_hip (char const * what, int code)
 }
 
 char const * drb_amd_last_error (void) { return last_error; }
+
+static DrbAmd_Status fetch_fault (DrbAmd_Batch * batch, void * hip_stream);
 
 /* ---- plan -> device chain --------------------------------------------------- */
 
@@ -340,6 +351,9 @@ static int build_launches (DrbAmd_Batch_Config const * config, Drb_Plan const * 
         {
             Drb_Fast_Chain collapsed = launch->fast;
 
+            launch->staged = launch->fast;
+            launch->has_staged = 1;
+
             if (drb_plan_collapse_geometry(&collapsed, fast_lds_budget))
             {
                 /* the same filter on the half-precision matrix instruction where
@@ -364,10 +378,13 @@ static int build_launches (DrbAmd_Batch_Config const * config, Drb_Plan const * 
     return count;
 }
 
-/* what the launches hand to the matrix core per target sample of the whole chain */
-static double issued_flops (Fast_Launch const * launches, int count)
+/* what the launches hand to the matrix core per target sample of the whole chain;
+ * *half_part: the share of it that runs on the half-precision instruction */
+static double issued_flops (Fast_Launch const * launches, int count, double * half_part)
 {
     double total = 0.0;
+
+    *half_part = 0.0;
 
     for (int i = 0; i < count; i++)
     {
@@ -385,7 +402,10 @@ static double issued_flops (Fast_Launch const * launches, int count)
         if (fast->kind == 4)
         {
             /* four 16 x 16 x 32 products of 16384 flop per row block and step */
-            total += 4.0 * 16384.0 * (double)fast->blocks * fast->chunks / (double)fast->tile_frames * launches[i].rate_ratio;
+            double const flops = 4.0 * 16384.0 * (double)fast->blocks * fast->chunks / (double)fast->tile_frames * launches[i].rate_ratio;
+
+            total += flops;
+            *half_part += flops;
             continue;
         }
 
@@ -442,9 +462,27 @@ DrbAmd_Status drb_amd_plan_info (DrbAmd_Batch_Config const * config, DrbAmd_Plan
     info->fast_path = count > 0;
     info->fast_launches = count;
     info->fast_tile_frames = count > 0 ? launches[count - 1].fast.tile_frames : 0;
-    info->fast_issued_flops_per_output_sample = issued_flops(launches, count);
+    info->fast_issued_flops_per_output_sample = issued_flops(launches, count, &info->fast_issued_half_flops_per_output_sample);
 
     for (int i = 0; i < count; i++) if (launches[i].fast.kind >= 3) info->fast_collapsed = launches[i].fast.kind - 2;
+
+    /* the kernel that does most of the work */
+    {
+        char const * name = "drb_cascade_kernel";
+
+        for (int i = 0; i < count; i++)
+        {
+            int const kind = launches[i].fast.kind;
+
+            if (i == 0 || launches[i].has_sinc)
+            {
+                name = kind == 4 ? "drb_split_kernel" : kind == 3 ? "drb_collapsed_kernel" : kind == 2 ? "drb_interpolate_kernel"
+                     : kind == 1 ? "drb_decimate_kernel" : "drb_fast_kernel";
+            }
+        }
+
+        snprintf(info->kernel_name, sizeof(info->kernel_name), "%s", name);
+    }
 
     free(launches);
 
@@ -531,6 +569,8 @@ static void release (DrbAmd_Batch * batch)
 
     if (batch->kernel_start) drb_hip_event_destroy(batch->kernel_start);
     if (batch->kernel_stop) drb_hip_event_destroy(batch->kernel_stop);
+    if (batch->step_start) drb_hip_event_destroy(batch->step_start);
+    if (batch->step_stop) drb_hip_event_destroy(batch->step_stop);
     if (batch->history[0]) drb_hip_free(batch->history[0]);
     if (batch->history[1]) drb_hip_free(batch->history[1]);
     if (batch->calls_device) drb_hip_free(batch->calls_device);
@@ -583,6 +623,7 @@ DrbAmd_Status drb_amd_batch_create (DrbAmd_Batch_Config const * config, DrbAmd_B
     batch->config = *config;
     batch->plan = plan;
     batch->device = device;
+    batch->last_slot = -1;
     batch->sample_bytes = config->sample_type == drb_amd_sample_i16 ? 2 : 4;
 
     drb_plan_geometry(&plan, lds_budget, &batch->geometry);
@@ -591,7 +632,7 @@ DrbAmd_Status drb_amd_batch_create (DrbAmd_Batch_Config const * config, DrbAmd_B
     batch->launch_count = build_launches(config, &plan, batch->launches);
 
     /* the first launch reads the history the batch keeps for the whole chain */
-    if (batch->launch_count > 0) batch->launches[0].fast.history = batch->geometry.history_frames;
+    if (batch->launch_count > 0) batch->launches[0].fast.history = batch->launches[0].staged.history = batch->geometry.history_frames;
 
     /* timing diagnostics only: skip phases of the fast kernel (results are wrong) */
     char const * const ablate = getenv("DRB_AMD_FAST_ABLATE");
@@ -605,6 +646,9 @@ DrbAmd_Status drb_amd_batch_create (DrbAmd_Batch_Config const * config, DrbAmd_B
         batch->launches[i].fast.tile_stride = stride ? atoi(stride) : 0;
         batch->launches[i].fast.no_carry = no_carry ? atoi(no_carry) : 0;
         batch->launches[i].fast.rebuild_tiles = getenv("DRB_AMD_FAST_REBUILD_TILES") ? atoi(getenv("DRB_AMD_FAST_REBUILD_TILES")) : 0;
+        batch->launches[i].staged.ablate = batch->launches[i].fast.ablate;
+        batch->launches[i].staged.tile_stride = batch->launches[i].fast.tile_stride;
+        batch->launches[i].staged.no_carry = batch->launches[i].fast.no_carry;
     }
 
     size_t const n = (size_t)config->stream_count;
@@ -790,9 +834,11 @@ static int collapse_grow_device (void ** pointer, size_t * room, size_t wanted, 
 static DrbAmd_Status collapse_prepare
     (
         DrbAmd_Batch * batch, Fast_Launch const * launch, Drb_Device_Call const * calls, int slot,
-        void * hip_stream, int * max_stretches_out, int * job_count_out
+        void * hip_stream, int * max_stretches_out, int * job_count_out, int * too_many_out
     )
 {
+    *too_many_out = 0;
+
     Drb_Fast_Chain const * const fast = &launch->fast;
     int const n = batch->config.stream_count;
     int const wanted = fast->rebuild_tiles > 0 ? fast->rebuild_tiles
@@ -886,6 +932,15 @@ static DrbAmd_Status collapse_prepare
 
             if (found < 0)
             {
+                /* A set per phase and stretch: with very many phases apart (thousands of
+                 * streams, each cut differently) the sets would outweigh the samples.
+                 * Such a step runs the three stages apart, which need no sets. */
+                if (((size_t)job_count + 1) * (size_t)drb_hip_collapse_set_words(fast) * sizeof(unsigned int) > collapse_set_bytes_limit)
+                {
+                    *too_many_out = 1;
+                    return drb_amd_ok;
+                }
+
                 if (!drb_plan_collapse_job(fast, rest, parity, &jobs[job_count]))
                 {
                     return fail(drb_amd_error_device, "stream %d: filter windows do not fit the kernel's geometry", s);
@@ -973,8 +1028,6 @@ DrbAmd_Status drb_amd_batch_process
     {
         if ((code = drb_hip_event_synchronize(batch->slot_done[slot])) != 0) return fail_hip("hipEventSynchronize", code);
         batch->slot_pending[slot] = 0;
-
-        if (*batch->fault_host) return fail(drb_amd_error_device, "kernel range check failed (code %d)", *batch->fault_host);
     }
 
     Drb_Device_Call * const calls = batch->calls_host[slot];
@@ -1060,23 +1113,41 @@ DrbAmd_Status drb_amd_batch_process
     int const tile = batch->geometry.tile_frames;
 
     int collapse_stretches = 1, collapse_job_count = 0;
+    int apart [max_launches];   /* 1: this step runs the launch's three stages apart */
 
     HOST_MARK(1);
 
     for (int l = 0; l < launches; l++)
     {
+        apart[l] = 0;
+
         if (fast && batch->launches[l].fast.kind >= 3)
         {
+            char const * const limit = getenv("DRB_AMD_FAST_APART");   /* diagnostic: 1 = always */
+
+            if (limit && atoi(limit) == 1 && batch->launches[l].has_staged) { apart[l] = 1; continue; }
+
             DrbAmd_Status const status = collapse_prepare(batch, &batch->launches[l], calls + (size_t)l * n, slot, hip_stream,
-                                                          &collapse_stretches, &collapse_job_count);
+                                                          &collapse_stretches, &collapse_job_count, &apart[l]);
 
             if (status != drb_amd_ok) return status;
+            if (apart[l] && !batch->launches[l].has_staged) return fail(drb_amd_error_out_of_memory, "too many different phases for coefficient sets");
         }
     }
 
     HOST_MARK(2);
 
-    code = drb_hip_upload_async(batch->calls_device, calls, (size_t)n * launches * sizeof(Drb_Device_Call), hip_stream);
+    /* A batch has one set of descriptors, histories and coefficient sets: a step on
+     * another stream than the last one waits for that one first. */
+    code = 0;
+
+    if (batch->last_slot >= 0 && batch->last_stream != hip_stream && batch->slot_pending[batch->last_slot])
+    {
+        code = drb_hip_stream_wait_event(hip_stream, batch->slot_done[batch->last_slot]);
+    }
+
+    if (!code && batch->timing) code = drb_hip_event_record(batch->step_start, hip_stream);
+    if (!code) code = drb_hip_upload_async(batch->calls_device, calls, (size_t)n * launches * sizeof(Drb_Device_Call), hip_stream);
 
     /* coefficient sets of the step: they depend on the streams' phases only, not
      * on their samples (built in front of the timed region, which is the filter
@@ -1084,7 +1155,7 @@ DrbAmd_Status drb_amd_batch_process
      * was measured far slower: every cross-stream wait cost most of a millisecond) */
     for (int l = 0; l < launches && !code; l++)
     {
-        if (fast && batch->launches[l].fast.kind >= 3)
+        if (fast && batch->launches[l].fast.kind >= 3 && !apart[l])
         {
             code = drb_hip_launch_collapse_build(&batch->launches[l].fast, batch->collapse_jobs, collapse_job_count,
                                                  batch->collapse_sets, batch->fault_device, hip_stream);
@@ -1098,16 +1169,17 @@ DrbAmd_Status drb_amd_batch_process
         for (int l = 0; l < launches && !code; l++)
         {
             Fast_Launch const * const launch = &batch->launches[l];
+            Drb_Fast_Chain const * const shape = apart[l] ? &launch->staged : &launch->fast;
             Drb_Device_Call const * const launch_calls = batch->calls_device + (size_t)l * n;
             long long const source_stride = l == 0 ? source_channel_stride : batch->launches[l - 1].output_frames;
             long long const target_stride = l == launches - 1 ? target_channel_stride : launch->output_frames;
-            int const fast_tile = launch->fast.tile_frames;
+            int const fast_tile = shape->tile_frames;
 
-            if (launch->fast.kind >= 3)
+            if (shape->kind >= 3)
             {
                 code = drb_hip_launch_collapsed
                 (
-                    &launch->fast, launch_calls, n, (int)((most[l] + fast_tile - 1) / fast_tile),
+                    shape, launch_calls, n, (int)((most[l] + fast_tile - 1) / fast_tile),
                     l == 0 ? history_in : launch->history[current], source_stride, target_stride,
                     batch->collapse_jobs, batch->collapse_spots, collapse_stretches, batch->collapse_sets,
                     batch->collapse_zeros, batch->fault_device, hip_stream
@@ -1115,7 +1187,7 @@ DrbAmd_Status drb_amd_batch_process
             }
             else code = drb_hip_launch_fast
             (
-                &launch->fast, launch_calls, n, (int)((most[l] + fast_tile - 1) / fast_tile),
+                shape, launch_calls, n, (int)((most[l] + fast_tile - 1) / fast_tile),
                 l == 0 ? history_in : launch->history[current], source_stride, target_stride,
                 batch->fault_device, hip_stream
             );
@@ -1157,7 +1229,7 @@ DrbAmd_Status drb_amd_batch_process
         );
     }
 
-    if (!code) code = drb_hip_download_async(batch->fault_host, batch->fault_device, sizeof(int), hip_stream);
+    if (!code && batch->timing) code = drb_hip_event_record(batch->step_stop, hip_stream);
     if (!code) code = drb_hip_event_record(batch->slot_done[slot], hip_stream);
 
     if (code) return fail_hip("launch", code);
@@ -1166,6 +1238,8 @@ DrbAmd_Status drb_amd_batch_process
     host_steps++;
 
     batch->slot_pending[slot] = 1;
+    batch->last_slot = slot;
+    batch->last_stream = hip_stream;
     batch->slot = (slot + 1) % ring_slots;
     batch->history_current ^= 1;
 
@@ -1347,6 +1421,17 @@ DrbAmd_Status drb_amd_batch_process_host_dense
 
     if (status != drb_amd_ok) return status;
     if (drained_in || drained_work || drained_out) return fail_hip("host feed", drained_in ? drained_in : drained_work ? drained_work : drained_out);
+
+    return fetch_fault(batch, work);
+}
+
+/* Waits for `hip_stream` and brings the kernels' fault word over. */
+static DrbAmd_Status fetch_fault (DrbAmd_Batch * batch, void * hip_stream)
+{
+    int code = drb_hip_download_async(batch->fault_host, batch->fault_device, sizeof(int), hip_stream);
+
+    if (!code) code = drb_hip_stream_synchronize(hip_stream);
+    if (code) return fail_hip("hipStreamSynchronize", code);
     if (*batch->fault_host) return fail(drb_amd_error_device, "kernel range check failed (code %d)", *batch->fault_host);
 
     return drb_amd_ok;
@@ -1358,12 +1443,9 @@ DrbAmd_Status drb_amd_batch_synchronize (DrbAmd_Batch * batch, void * hip_stream
 
     int code = drb_hip_set_device(batch->device);
 
-    if (!code) code = drb_hip_stream_synchronize(hip_stream);
-    if (code) return fail_hip("hipStreamSynchronize", code);
+    if (code) return fail_hip("hipSetDevice", code);
 
-    if (*batch->fault_host) return fail(drb_amd_error_device, "kernel range check failed (code %d)", *batch->fault_host);
-
-    return drb_amd_ok;
+    return fetch_fault(batch, hip_stream);
 }
 
 DrbAmd_Status drb_amd_batch_time_kernels (DrbAmd_Batch * batch, int enable)
@@ -1376,6 +1458,8 @@ DrbAmd_Status drb_amd_batch_time_kernels (DrbAmd_Batch * batch, int enable)
 
         if (!code) code = drb_hip_timing_event_create(&batch->kernel_start);
         if (!code) code = drb_hip_timing_event_create(&batch->kernel_stop);
+        if (!code) code = drb_hip_timing_event_create(&batch->step_start);
+        if (!code) code = drb_hip_timing_event_create(&batch->step_stop);
         if (code) return fail_hip("hipEventCreate", code);
     }
 
@@ -1393,6 +1477,19 @@ DrbAmd_Status drb_amd_batch_kernel_ms (DrbAmd_Batch * batch, float * millisecond
     int code = drb_hip_event_synchronize(batch->kernel_stop);
 
     if (!code) code = drb_hip_event_elapsed_ms(milliseconds, batch->kernel_start, batch->kernel_stop);
+    if (code) return fail_hip("hipEventElapsedTime", code);
+
+    return drb_amd_ok;
+}
+
+DrbAmd_Status drb_amd_batch_step_ms (DrbAmd_Batch * batch, float * milliseconds)
+{
+    if (!batch || !milliseconds) return fail(drb_amd_error_bad_argument, "null argument");
+    if (!batch->kernel_timed) return fail(drb_amd_error_bad_argument, "no timed step yet");
+
+    int code = drb_hip_event_synchronize(batch->step_stop);
+
+    if (!code) code = drb_hip_event_elapsed_ms(milliseconds, batch->step_start, batch->step_stop);
     if (code) return fail_hip("hipEventElapsedTime", code);
 
     return drb_amd_ok;

@@ -51,7 +51,8 @@ class PlanInfo(ctypes.Structure):
                 ("flops_per_output_sample", ctypes.c_double),
                 ("bytes_per_output_sample", ctypes.c_double),
                 ("fast_path", ctypes.c_int), ("fast_tile_frames", ctypes.c_int), ("fast_launches", ctypes.c_int),
-                ("fast_issued_flops_per_output_sample", ctypes.c_double), ("fast_collapsed", ctypes.c_int)]
+                ("fast_issued_flops_per_output_sample", ctypes.c_double), ("fast_collapsed", ctypes.c_int),
+                ("fast_issued_half_flops_per_output_sample", ctypes.c_double), ("kernel_name", ctypes.c_char * 48)]
 
     def stages(self):
         kinds = {1: "up2x", 2: "down2x", 3: "sinc", 4: "slicer"}
@@ -81,6 +82,7 @@ lib.drb_amd_batch_process_host_dense.argtypes = [ctypes.c_void_p,
 lib.drb_amd_batch_synchronize.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 lib.drb_amd_batch_time_kernels.argtypes = [ctypes.c_void_p, ctypes.c_int]
 lib.drb_amd_batch_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+lib.drb_amd_batch_step_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
 lib.drb_amd_plan_info.argtypes = [ctypes.POINTER(BatchConfig), ctypes.POINTER(PlanInfo)]
 lib.drb_audio_converter_alignment_and_size.restype = ctypes.c_bool
 lib.drb_audio_converter_alignment_and_size.argtypes = [ctypes.c_int] * 7 + [
@@ -182,6 +184,13 @@ class Batch:
                                         ctypes.c_void_p(stream or 0)))
         return list(produced)
 
+    def process_arrays(self, src, source_channel_stride, sf, dst, target_channel_stride, tf, produced, stream=None):
+        """drb_amd_batch_process on ctypes arrays the caller keeps ((c_void_p * n), (c_int * n)):
+        nothing is built per call."""
+        check(lib.drb_amd_batch_process(self.handle, src, source_channel_stride, sf, dst,
+                                        target_channel_stride, tf, produced,
+                                        ctypes.c_void_p(stream or 0)))
+
     def process_dense(self, source_ptr, source_stream_stride, source_channel_stride,
                       target_ptr, target_stream_stride, target_channel_stride,
                       frames, capacity, stream=None, produced=None):
@@ -206,6 +215,11 @@ class Batch:
     def kernel_ms(self):
         ms = ctypes.c_float()
         check(lib.drb_amd_batch_kernel_ms(self.handle, ctypes.byref(ms)))
+        return ms.value
+
+    def step_ms(self):
+        ms = ctypes.c_float()
+        check(lib.drb_amd_batch_step_ms(self.handle, ctypes.byref(ms)))
         return ms.value
 
     def synchronize(self, stream=None):

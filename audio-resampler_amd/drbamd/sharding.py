@@ -3,6 +3,51 @@
 Streams are independent converters, so a job over `total` streams is split into
 contiguous stream-id ranges, one per rank (one process per GPU); no data moves
 between ranks.  torch.distributed is used only to agree on timings."""
+import os
+import socket
+import subprocess
+import sys
+
+
+def spawn_ranks(world, script, argv, check_devices=True):
+    """Starts `world` copies of `script argv`, one per rank, with the rendezvous a
+    launcher would set (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR 127.0.0.1, a free
+    MASTER_PORT).  The caller must not have touched a GPU yet: the children are
+    new processes, nothing is re-executed.  Their output passes through; returns
+    the worst exit code."""
+    if check_devices:
+        import torch
+
+        have = torch.cuda.device_count()   # (counts devices without initialising any)
+        if have < world:
+            sys.stderr.write("%d GPUs asked for, %d visible\n" % (world, have))
+            return 2
+    with socket.socket() as probe:
+        probe.bind(("127.0.0.1", 0))
+        port = probe.getsockname()[1]
+    children = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        children.append(subprocess.Popen([sys.executable, os.path.abspath(script)] + list(argv), env=env))
+    return max(child.wait() for child in children)
+
+
+def rank_of_environment():
+    """(rank, local rank, world size) as a launcher set them; (0, 0, 1) outside one."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def streams_of_rank(scaling, per_gpu, total, rank, world):
+    """(streams this rank owns, first stream id, streams of the whole job).  weak:
+    every rank owns `per_gpu` streams; strong: `total` streams (0 = 8 x per_gpu) are
+    split into contiguous ranges."""
+    if scaling == "strong":
+        total = total or 8 * per_gpu
+        first, last = shard_range(total, rank, world)
+        return last - first, first, total
+    return per_gpu, rank * per_gpu, per_gpu * world
 
 
 def shard_range(total, rank, world):

@@ -249,7 +249,10 @@ extern DrbAmd_Status drb_amd_batch_query
  *
  * Work is enqueued on `hip_stream` (a hipStream_t, NULL = the default stream)
  * and the call returns without waiting for it.  Per-stream filter history and
- * phase carry over to the next call.  At most 2^24 frames per stream per call. */
+ * phase carry over to the next call.  At most 2^24 frames per stream per call.
+ * Steps of one batch run in the order of the calls: a call on another stream
+ * than the one before makes its stream wait for that step.  Calls on one batch
+ * must not overlap in time (one thread at a time per batch). */
 extern DrbAmd_Status drb_amd_batch_process
     (
         DrbAmd_Batch * batch,
@@ -305,6 +308,9 @@ extern DrbAmd_Status drb_amd_batch_synchronize (DrbAmd_Batch * batch, void * hip
  * for the most recent bracket and returns its duration in milliseconds. */
 extern DrbAmd_Status drb_amd_batch_time_kernels (DrbAmd_Batch * batch, int enable);
 extern DrbAmd_Status drb_amd_batch_kernel_ms (DrbAmd_Batch * batch, float * milliseconds);
+/* The same for everything the most recent step ran on the device: descriptor
+ * upload, coefficient sets, filter kernels, history update. */
+extern DrbAmd_Status drb_amd_batch_step_ms (DrbAmd_Batch * batch, float * milliseconds);
 
 /* Planner facts for a configuration (host only, no device needed): the DSP
  * stages in data-flow order and the sizes the kernels derive from them. */
@@ -333,7 +339,15 @@ typedef struct DrbAmd_Plan_Info
     int fast_collapsed;     /* 1: [up2x] sinc [down2x] run as ONE time-varying filter
                                from source to target frames (its coefficients are
                                the product of the three stages', so it spends fewer
-                               multiply-adds per sample than upstream's cascade)   */
+                               multiply-adds per sample than upstream's cascade);
+                               2: that filter on the half-precision matrix
+                               instruction, every float32 carried as two halves   */
+    double fast_issued_half_flops_per_output_sample;  /* the part of
+                               fast_issued_flops_per_output_sample that runs on the
+                               half-precision instruction (16 times the float32
+                               instruction's rate)                                 */
+    char kernel_name [48];  /* the kernel that does most of the work of a step in
+                               the configuration's arithmetic mode                 */
 }
 DrbAmd_Plan_Info;
 

@@ -69,3 +69,44 @@ def test_shard_ranges_partition_the_streams():
             assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
             sizes = [b - a for a, b in edges]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_launcher_starts_ranks_that_shard_and_reduce(tmp_path, capfd):
+    """The path `python3 bench.py --gpus N` takes outside a launcher, rehearsed on
+    the CPU: drbamd.sharding.spawn_ranks starts the ranks with a launcher's
+    environment, each takes its contiguous share of a strongly scaled job, and
+    the reduction is the slowest rank's time and the summed frames."""
+    sys.path.insert(0, os.path.join(support.ROOT, "audio-resampler_amd"))
+    import json
+
+    from drbamd import sharding
+
+    worker = os.path.join(support.ROOT, "tests", "sharding_worker.py")
+    for scaling, per_gpu, total, streams in (("strong", 0, 7, 7), ("weak", 3, 0, 6)):
+        out = tmp_path / scaling
+        out.mkdir()
+        code = sharding.spawn_ranks(2, worker, [scaling, str(per_gpu), str(total), str(out)], check_devices=False)
+        assert code == 0
+        line = json.loads([l for l in capfd.readouterr().out.splitlines() if l.startswith("{")][-1])
+        status, plan = support.oracle_plan(44100, 48000, 2, 4, 64, PUSH, support.GOOD)
+        frames = 0
+        for s in range(streams):
+            want = support.oracle_push(plan, support.white_noise(2, 1500 + 10 * s, 900 + s))
+            got = np.load(out / ("stream%03d.npy" % s))
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+            frames += want.shape[1]
+        assert line["world"] == 2 and line["streams"] == streams and line["first"] == 0
+        assert line["slowest"] == 2.0 and line["frames"] == float(frames)
+        assert line["mine"] == (4 if scaling == "strong" else 3)
+
+
+def test_bench_starts_its_own_ranks_only_outside_a_launcher():
+    """bench.py --gpus 2 without WORLD_SIZE goes to the launcher (and fails loudly
+    here, where no GPU is visible) before importing anything that touches a GPU."""
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    done = subprocess.run([sys.executable, os.path.join(support.ROOT, "bench.py"), "--gpus", "2"],
+                          env=env, capture_output=True, text=True, timeout=120)
+    assert done.returncode == 2
+    assert "2 GPUs asked for, 0 visible" in done.stderr
