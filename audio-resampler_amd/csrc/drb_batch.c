@@ -24,6 +24,7 @@ enum { ring_slots = 4, max_step_frames = 1 << 24, fault_words = 128, host_slots 
 enum { max_launches = drb_max_stages };
 
 static size_t const collapse_set_bytes_limit = (size_t)1 << 30;   /* of coefficient sets per step */
+static size_t const static_host_bytes = (size_t)256 << 10;       /* pinned, per ring slot, from creation on */
 
 typedef struct Fast_Launch
 {
@@ -105,6 +106,12 @@ struct DrbAmd_Batch
 
     void * last_stream;               /* stream of the step enqueued last, and whether there was one */
     int last_slot;
+
+    /* the library's static device workspace on this batch's GPU, and whether the
+     * call in progress must live within it (drb_amd_batch_process_dense_static) */
+    void * static_base;
+    size_t static_bytes;
+    int no_alloc;
 };
 
 /* ---- where the host's time goes (DRB_AMD_HOST_PROFILE=1 prints at destroy) ---- */
@@ -693,6 +700,27 @@ DrbAmd_Status drb_amd_batch_create (DrbAmd_Batch_Config const * config, DrbAmd_B
         if (!code) code = drb_hip_alloc((void **)&batch->launches[i].history[1], bytes);
     }
 
+    /* tables every step of a modest size fits, so that a call that may not
+     * allocate finds them there */
+    for (int i = 0; i < ring_slots && !code; i++)
+    {
+        code = drb_hip_host_alloc(&batch->collapse_host[i], static_host_bytes);
+        if (!code) batch->collapse_host_bytes[i] = static_host_bytes;
+    }
+
+    if (!code)
+    {
+        size_t hash_size = 64;
+
+        while (hash_size < 16 * n + 2) hash_size *= 2;
+
+        batch->collapse_hash = malloc(hash_size * sizeof(int));
+        batch->collapse_hash_room = batch->collapse_hash ? hash_size : 0;
+    }
+
+    /* the static workspace's address on this GPU (looked up once per device) */
+    if (!code) code = drb_hip_static_workspace(device, &batch->static_base, &batch->static_bytes);
+
     if (!code) code = drb_hip_alloc((void **)&batch->collapse_zeros, 256);
     if (!code) code = drb_hip_memset_async(batch->collapse_zeros, 0, 256, 0);
     if (!code) code = drb_hip_memset_async(batch->fault_device, 0, fault_words * sizeof(long long), 0);
@@ -807,9 +835,12 @@ DrbAmd_Status drb_amd_batch_query (DrbAmd_Batch const * batch, int const * frame
 
 /* ---- collapsed launch: which coefficient sets a step needs ------------------- */
 
-static int collapse_grow_device (void ** pointer, size_t * room, size_t wanted, size_t element, void * hip_stream)
+enum { code_no_room = -77 };   /* not a HIP code: a buffer would have to grow in a call that may not allocate */
+
+static int collapse_grow_device (void ** pointer, size_t * room, size_t wanted, size_t element, void * hip_stream, int may_grow)
 {
     if (wanted <= *room) return 0;
+    if (!may_grow) return code_no_room;
 
     int code = drb_hip_stream_synchronize(hip_stream);   /* earlier steps may still read the old one */
 
@@ -860,6 +891,8 @@ static DrbAmd_Status collapse_prepare
 
     if (host_bytes > batch->collapse_host_bytes[slot])
     {
+        if (batch->no_alloc) return fail(drb_amd_error_capacity, "the step's coefficient tables do not fit the pinned memory the batch was created with");
+
         if (batch->collapse_host[slot]) drb_hip_host_free(batch->collapse_host[slot]);
 
         batch->collapse_host[slot] = 0;
@@ -879,6 +912,8 @@ static DrbAmd_Status collapse_prepare
 
     if (hash_size > batch->collapse_hash_room)
     {
+        if (batch->no_alloc) return fail(drb_amd_error_capacity, "too many stretches for the tables the batch was created with");
+
         free(batch->collapse_hash);
         batch->collapse_hash = malloc(hash_size * sizeof(int));
         batch->collapse_hash_room = batch->collapse_hash ? hash_size : 0;
@@ -935,7 +970,9 @@ static DrbAmd_Status collapse_prepare
                 /* A set per phase and stretch: with very many phases apart (thousands of
                  * streams, each cut differently) the sets would outweigh the samples.
                  * Such a step runs the three stages apart, which need no sets. */
-                if (((size_t)job_count + 1) * (size_t)drb_hip_collapse_set_words(fast) * sizeof(unsigned int) > collapse_set_bytes_limit)
+                size_t const limit = batch->no_alloc ? batch->collapse_sets_room * sizeof(unsigned int) : collapse_set_bytes_limit;
+
+                if (((size_t)job_count + 2) * (size_t)drb_hip_collapse_set_words(fast) * sizeof(unsigned int) > limit)
                 {
                     *too_many_out = 1;
                     return drb_amd_ok;
@@ -959,11 +996,12 @@ static DrbAmd_Status collapse_prepare
         }
     }
 
-    code = collapse_grow_device((void **)&batch->collapse_spots, &batch->collapse_spots_room, (size_t)n * max_stretches, sizeof(Drb_Collapse_Spot), hip_stream);
-    if (!code) code = collapse_grow_device((void **)&batch->collapse_jobs, &batch->collapse_jobs_room, (size_t)job_count + 1, sizeof(Drb_Collapse_Job), hip_stream);
+    code = collapse_grow_device((void **)&batch->collapse_spots, &batch->collapse_spots_room, (size_t)n * max_stretches, sizeof(Drb_Collapse_Spot), hip_stream, !batch->no_alloc);
+    if (!code) code = collapse_grow_device((void **)&batch->collapse_jobs, &batch->collapse_jobs_room, (size_t)job_count + 1, sizeof(Drb_Collapse_Job), hip_stream, !batch->no_alloc);
     if (!code) code = collapse_grow_device((void **)&batch->collapse_sets, &batch->collapse_sets_room,
-                                           ((size_t)job_count + 1) * (size_t)drb_hip_collapse_set_words(fast), sizeof(unsigned int), hip_stream);
+                                           ((size_t)job_count + 1) * (size_t)drb_hip_collapse_set_words(fast), sizeof(unsigned int), hip_stream, !batch->no_alloc);
 
+    if (code == code_no_room) return fail(drb_amd_error_capacity, "the step's coefficient tables do not fit the static workspace");
     if (code) return fail(drb_amd_error_out_of_memory, "coefficient sets: %s", drb_hip_error_text(code));
 
     code = drb_hip_upload_async(batch->collapse_spots, spots, spots_bytes, hip_stream);
@@ -1062,6 +1100,8 @@ DrbAmd_Status drb_amd_batch_process
 
         if (most[l] > launch->output_frames)
         {
+            if (batch->no_alloc) return fail(drb_amd_error_capacity, "a buffer between this chain's launches would have to grow");
+
             long long const frames = (most[l] + most[l] / 4 + 255) / 256 * 256;
 
             if ((code = drb_hip_stream_synchronize(hip_stream)) != 0) return fail_hip("hipStreamSynchronize", code);
@@ -1282,6 +1322,71 @@ DrbAmd_Status drb_amd_batch_process_dense
         batch->dense_target, target_channel_stride, pull ? batch->dense_frames : batch->dense_capacity,
         produced_each ? produced_each : batch->dense_produced, hip_stream
     );
+}
+
+/* ---- the same without allocating --------------------------------------------- */
+
+/* How the static workspace is cut up: step descriptors, then the coefficient
+ * tables of a collapsed launch (stretch table, jobs, sets). */
+enum { static_calls_bytes = 1 << 20, static_spots_bytes = 1 << 20, static_jobs_bytes = 256 << 10 };
+
+DrbAmd_Status drb_amd_batch_process_dense_static
+    (
+        DrbAmd_Batch * batch,
+        void const * source_base, long long source_stream_stride, long long source_channel_stride,
+        void * target_base, long long target_stream_stride, long long target_channel_stride,
+        int frames, int capacity,
+        int * produced_each,
+        void * hip_stream
+    )
+{
+    if (!batch) return fail(drb_amd_error_bad_argument, "null argument");
+
+    size_t const fixed = static_calls_bytes + static_spots_bytes + static_jobs_bytes;
+
+    if (!batch->static_base || batch->static_bytes <= fixed) return fail(drb_amd_error_device, "the static workspace is not available");
+
+    size_t const launches = batch->config.arithmetic == drb_amd_arithmetic_fast && batch->launch_count > 0 ? (size_t)batch->launch_count : 1;
+
+    if ((size_t)batch->config.stream_count * launches * sizeof(Drb_Device_Call) > static_calls_bytes)
+    {
+        return fail(drb_amd_error_capacity, "%d streams x %d launches: more step descriptors than the static workspace holds (%d)",
+                    batch->config.stream_count, (int)launches, (int)(static_calls_bytes / sizeof(Drb_Device_Call)));
+    }
+
+    /* this call's tables live in the workspace instead of the batch's own buffers */
+    Drb_Device_Call * const own_calls = batch->calls_device;
+    Drb_Collapse_Spot * const own_spots = batch->collapse_spots;
+    Drb_Collapse_Job * const own_jobs = batch->collapse_jobs;
+    unsigned int * const own_sets = batch->collapse_sets;
+    size_t const own_spots_room = batch->collapse_spots_room, own_jobs_room = batch->collapse_jobs_room, own_sets_room = batch->collapse_sets_room;
+    char * const base = batch->static_base;
+
+    batch->calls_device = (Drb_Device_Call *)base;
+    batch->collapse_spots = (Drb_Collapse_Spot *)(base + static_calls_bytes);
+    batch->collapse_spots_room = static_spots_bytes / sizeof(Drb_Collapse_Spot);
+    batch->collapse_jobs = (Drb_Collapse_Job *)(base + static_calls_bytes + static_spots_bytes);
+    batch->collapse_jobs_room = static_jobs_bytes / sizeof(Drb_Collapse_Job);
+    batch->collapse_sets = (unsigned int *)(base + fixed);
+    batch->collapse_sets_room = (batch->static_bytes - fixed) / sizeof(unsigned int);
+    batch->no_alloc = 1;
+
+    DrbAmd_Status const status = drb_amd_batch_process_dense
+    (
+        batch, source_base, source_stream_stride, source_channel_stride,
+        target_base, target_stream_stride, target_channel_stride, frames, capacity, produced_each, hip_stream
+    );
+
+    batch->no_alloc = 0;
+    batch->calls_device = own_calls;
+    batch->collapse_spots = own_spots;
+    batch->collapse_jobs = own_jobs;
+    batch->collapse_sets = own_sets;
+    batch->collapse_spots_room = own_spots_room;
+    batch->collapse_jobs_room = own_jobs_room;
+    batch->collapse_sets_room = own_sets_room;
+
+    return status;
 }
 
 /* ---- host-fed: copy in, convert and copy out in overlapping slices ---------- */

@@ -148,6 +148,9 @@ int drb_hip_device_count (int * count);
 int drb_hip_get_device (int * device);
 int drb_hip_set_device (int device);
 int drb_hip_device_is_gfx950 (int device, int * yes, int * lds_bytes_per_block);
+/* The library's static device workspace on `device` (which must be the calling
+ * thread's current device): its address there and its size.  Allocates nothing. */
+int drb_hip_static_workspace (int device, void ** pointer, size_t * bytes);
 int drb_hip_alloc (void ** pointer, size_t bytes);
 int drb_hip_free (void * pointer);
 int drb_hip_host_alloc (void ** pointer, size_t bytes);

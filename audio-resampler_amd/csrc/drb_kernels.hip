@@ -17,6 +17,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "drb_hip.h"
 
 namespace
@@ -638,9 +640,48 @@ __global__ __launch_bounds__(kThreads) void drb_history_kernel
 
 } // namespace
 
+// ---- static workspace ---------------------------------------------------------------
+// Device memory of the library's own for callers that may not allocate (see
+// drb_amd_batch_process_dense_static): part of the code object, so every GPU
+// the library runs on holds its own copy from the first use to the end of the
+// process.  `scratch` as written in host code is only a handle for
+// hipGetSymbolAddress; what kernels and copies get is the address that call
+// returns, looked up once per device with that device current.
+constexpr size_t kScratchBytes = static_cast<size_t>(8) << 20;
+constexpr int kScratchDevices = 64;
+
+static __device__ __align__(256) unsigned char scratch [kScratchBytes];
+
+static void * scratch_address [kScratchDevices];
+static std::mutex scratch_lock;
+
 // ---- C ABI --------------------------------------------------------------------
 
 extern "C" {
+
+// The calling thread's current device must be `device`.
+int drb_hip_static_workspace (int device, void ** pointer, size_t * bytes)
+{
+    if (device < 0 || device >= kScratchDevices) return hipErrorInvalidDevice;
+
+    std::lock_guard<std::mutex> guard(scratch_lock);
+
+    if (!scratch_address[device])
+    {
+        void * address = nullptr;
+        hipError_t const status = hipGetSymbolAddress(&address, HIP_SYMBOL(scratch));
+
+        if (status != hipSuccess) return status;
+        if (!address) return hipErrorInvalidSymbol;
+
+        scratch_address[device] = address;
+    }
+
+    *pointer = scratch_address[device];
+    *bytes = kScratchBytes;
+
+    return 0;
+}
 
 int drb_hip_device_count (int * count) { return hipGetDeviceCount(count); }
 int drb_hip_get_device (int * device) { return hipGetDevice(device); }

@@ -75,6 +75,7 @@ lib.drb_amd_batch_process_dense.argtypes = [ctypes.c_void_p,
                                             ctypes.c_void_p, ctypes.c_longlong, ctypes.c_longlong,
                                             ctypes.c_void_p, ctypes.c_longlong, ctypes.c_longlong,
                                             ctypes.c_int, ctypes.c_int, c_int_p, ctypes.c_void_p]
+lib.drb_amd_batch_process_dense_static.argtypes = lib.drb_amd_batch_process_dense.argtypes
 lib.drb_amd_batch_process_host_dense.argtypes = [ctypes.c_void_p,
                                                  ctypes.c_void_p, ctypes.c_longlong, ctypes.c_longlong,
                                                  ctypes.c_void_p, ctypes.c_longlong, ctypes.c_longlong,
@@ -199,6 +200,16 @@ class Batch:
                                               ctypes.c_void_p(target_ptr), target_stream_stride,
                                               target_channel_stride, frames, capacity, produced,
                                               ctypes.c_void_p(stream or 0)))
+
+    def process_dense_static(self, source_ptr, source_stream_stride, source_channel_stride,
+                             target_ptr, target_stream_stride, target_channel_stride,
+                             frames, capacity, stream=None, produced=None):
+        """process_dense without any allocation (the library's static device workspace)."""
+        check(lib.drb_amd_batch_process_dense_static(self.handle, ctypes.c_void_p(source_ptr),
+                                                     source_stream_stride, source_channel_stride,
+                                                     ctypes.c_void_p(target_ptr), target_stream_stride,
+                                                     target_channel_stride, frames, capacity, produced,
+                                                     ctypes.c_void_p(stream or 0)))
 
     def process_host_dense(self, source_ptr, source_stream_stride, source_channel_stride,
                            target_ptr, target_stream_stride, target_channel_stride,

@@ -281,6 +281,35 @@ extern DrbAmd_Status drb_amd_batch_process_dense
         void * hip_stream
     );
 
+/* drb_amd_batch_process_dense for callers that may not allocate: code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has
+ * no counterpart upstream (whose converter owns no resources at all).  The
+ * same step, with the same results; but the device tables a step needs beyond
+ * the batch's per-stream state (step descriptors and, for the collapsed
+ * matrix-core kernels, the coefficient tables of the step) live in a static
+ * 8 MiB workspace inside the library's code object instead of buffers that
+ * grow on demand, and the call makes no hipMalloc / hipFree / hipHostMalloc
+ * and no host allocation either.  Limits, reported as drb_amd_error_capacity:
+ * stream_count x launches per step <= 26214 (1 MiB of step descriptors);
+ * stream_count x stretches of 64 tiles <= 131072; a chain of several launches
+ * must have run a step at least this long through drb_amd_batch_process before
+ * (its buffers between launches do not grow here).  Where the streams' phases
+ * differ so much that their coefficient sets exceed the workspace (about 47
+ * sets), the step runs the kernels that need none.  Every batch on a GPU
+ * shares that GPU's workspace: calls on DIFFERENT batches of one GPU must not
+ * overlap in time (calls on one batch are ordered by the library, as for
+ * drb_amd_batch_process); it keeps the last call's contents and is rewritten
+ * by every call before anything reads it. */
+extern DrbAmd_Status drb_amd_batch_process_dense_static
+    (
+        DrbAmd_Batch * batch,
+        void const * source_base, long long source_stream_stride, long long source_channel_stride,
+        void * target_base, long long target_stream_stride, long long target_channel_stride,
+        int frames, int capacity,
+        int * produced_each,
+        void * hip_stream
+    );
+
 /* The same with source and target in HOST memory (pinned memory copies at the
  * link's speed; pageable memory works, slowly): streams are handed to the
  * device in slices of about 128 MB, and one slice's copies run while another is

@@ -81,7 +81,7 @@ def test_library_exports_every_declared_symbol():
              "drb_audio_converter_work_memory_alignment_and_size", "drb_audio_converter_process",
              "drb_amd_converter_release", "drb_amd_batch_create", "drb_amd_batch_destroy",
              "drb_amd_batch_reset", "drb_amd_batch_query", "drb_amd_batch_process",
-             "drb_amd_batch_process_dense", "drb_amd_batch_process_host_dense", "drb_amd_batch_synchronize",
+             "drb_amd_batch_process_dense", "drb_amd_batch_process_dense_static", "drb_amd_batch_process_host_dense", "drb_amd_batch_synchronize",
              "drb_amd_plan_info",
              "drb_amd_batch_time_kernels", "drb_amd_batch_kernel_ms", "drb_amd_batch_step_ms",
              "drb_amd_plan_describe", "drb_amd_last_error"]

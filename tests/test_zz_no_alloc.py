@@ -1,0 +1,75 @@
+"""The entry point that allocates nothing, drb_amd_batch_process_dense_static,
+against drb_amd_batch_process_dense on the same inputs: two batches of one
+configuration, fed the same chunks, one through each entry point; two calls in
+a row, the second with a smaller input.  Both run the same kernels on the same
+data, so the outputs are compared bit for bit (which meets the parity bar of
+either arithmetic mode: the regular entry point's outputs are checked against
+the upstream converter by the other tests)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import support
+from support import PUSH
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+drbamd = pytest.importorskip("drbamd")
+
+CASES = [
+    ("exact", drbamd.EXACT, 44100, 48000, 2, support.GOOD, 5),
+    ("fast, collapsed matrix-core kernel", drbamd.FAST, 44100, 48000, 2, support.GOOD, 6),
+    ("fast, one decimator", drbamd.FAST, 96000, 48000, 8, support.GOOD, 3),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_static_entry_point_matches_the_regular_one(case):
+    _, arithmetic, src, dst, ch, quality, streams = case
+    config = drbamd.make_config(src, dst, ch, 256, 16, PUSH, quality, arithmetic=arithmetic, streams=streams)
+    regular, static = drbamd.Batch(config), drbamd.Batch(config)
+    calls = [3 * src // 256 * 256, 4096]   # the second call is the smaller one
+    total = sum(calls)
+    x = np.stack([support.white_noise(ch, total, 500 + s) for s in range(streams)])
+    source = torch.from_numpy(x).cuda()
+    capacity = regular.query([total] * streams)[0] + 4096
+    outputs = [torch.zeros((streams, ch, capacity), device="cuda:0") for _ in range(2)]
+    stream = torch.cuda.current_stream().cuda_stream
+    made = [0, 0]
+    at = 0
+    for frames in calls:
+        for which, (batch, entry) in enumerate(((regular, regular.process_dense), (static, static.process_dense_static))):
+            counts = (ctypes.c_int * streams)()
+            entry(source.data_ptr() + 4 * at, ch * total, total,
+                  outputs[which].data_ptr() + 4 * made[which], ch * capacity, capacity,
+                  frames, capacity - made[which], stream=stream, produced=counts)
+            assert len(set(counts)) == 1
+            made[which] += counts[0]
+        at += frames
+    regular.synchronize(stream)
+    static.synchronize(stream)
+    assert made[0] == made[1] > 0
+    want, got = outputs[0].cpu().numpy(), outputs[1].cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    if arithmetic == drbamd.EXACT:
+        status, plan = support.oracle_plan(src, dst, ch, 256, 16, PUSH, quality)
+        for s in range(streams):
+            upstream = support.oracle_push(plan, x[s])
+            assert np.array_equal(got[s, :, :made[1]].view(np.uint32), upstream.view(np.uint32))
+    regular.close()
+    static.close()
+
+
+def test_static_entry_point_rejects_what_does_not_fit():
+    """More step descriptors than the workspace holds: a clear error, nothing enqueued."""
+    streams = 30000
+    config = drbamd.make_config(44100, 48000, 1, 256, 16, PUSH, support.POOR, streams=streams)
+    batch = drbamd.Batch(config)
+    source = torch.zeros((streams, 1, 256), device="cuda:0")
+    target = torch.zeros((streams, 1, 1024), device="cuda:0")
+    with pytest.raises(drbamd.DrbError) as error:
+        batch.process_dense_static(source.data_ptr(), 256, 256, target.data_ptr(), 1024, 1024, 256, 1024)
+    assert "static workspace" in str(error.value)
+    batch.close()
