@@ -792,9 +792,9 @@ int drb_hip_launch_cascade
 
     size_t const dynamic = static_cast<size_t>(lds_bytes) + bank_floats * sizeof(float) + sizeof(Ranges);
 
-    static size_t raised = 0; // largest dynamic LDS size opted into so far
-
-    if (dynamic > 48 * 1024 && dynamic > raised)
+    // (the attribute is per device and batches may live on several: set on every
+    // launch that needs it, which is cheap, rather than remembered per process)
+    if (dynamic > 48 * 1024)
     {
         hipError_t const status = hipFuncSetAttribute
         (
@@ -803,8 +803,6 @@ int drb_hip_launch_cascade
         );
 
         if (status != hipSuccess) return status;
-
-        raised = dynamic;
     }
 
     long long const blocks = static_cast<long long>(stream_count) * max_tiles;
