@@ -92,7 +92,6 @@ struct DrbAmd_Batch
     Drb_Collapse_Job * collapse_jobs;          /* device                       */
     Drb_Collapse_Spot * collapse_spots;        /* device                       */
     unsigned int * collapse_sets;              /* device                       */
-    float * collapse_zeros;                    /* device: silence for loads that have no source */
     size_t collapse_jobs_room, collapse_spots_room, collapse_sets_room;   /* elements / words */
     void * collapse_host [ring_slots];         /* pinned: spots, then jobs     */
     size_t collapse_host_bytes [ring_slots];
@@ -238,7 +237,7 @@ static DrbAmd_Status resolve (DrbAmd_Batch_Config const * config, Drb_Plan * pla
     return drb_amd_ok;
 }
 
-enum { lds_budget = 56 * 1024, fast_lds_budget = 78 * 1024 };
+enum { lds_budget = 56 * 1024, fast_lds_budget = 78 * 1024, split_lds_budget = 160 * 1024 };
 
 /* ---- plan -> launches of the matrix-core path -------------------------------- */
 
@@ -348,36 +347,22 @@ static int build_launches (DrbAmd_Batch_Config const * config, Drb_Plan const * 
 
         if (!launch->fast.usable || !drb_hip_fast_kernel_exists(&launch->fast)) return 0;
 
-        /* [up] sinc [down] as one filter where that form applies and is the faster
-         * kernel (DRB_AMD_FAST_COLLAPSED, a diagnostic: 0 keeps the three stages
-         * everywhere, 1 collapses wherever a kernel image exists) */
-        char const * const wish = getenv("DRB_AMD_FAST_COLLAPSED");
-        int const forced = wish && atoi(wish) > 0, forbidden = wish && atoi(wish) == 0;
+        /* [up] sinc [down] as one filter on the half-precision matrix instruction
+         * where that form applies and its kernel fits (DRB_AMD_FAST_SPLIT=0, a
+         * diagnostic, keeps the three stages everywhere) */
+        char const * const wish = getenv("DRB_AMD_FAST_SPLIT");
 
-        if (launch->has_sinc && !forbidden)
+        if (launch->has_sinc && !(wish && atoi(wish) == 0))
         {
-            Drb_Fast_Chain collapsed = launch->fast;
+            Drb_Fast_Chain split = launch->fast;
 
             launch->staged = launch->fast;
             launch->has_staged = 1;
 
-            if (drb_plan_collapse_geometry(&collapsed, fast_lds_budget))
+            if (drb_plan_collapse_geometry(&split, split_lds_budget, 1)
+                && drb_plan_split_geometry(&split, split_lds_budget) && drb_hip_fast_kernel_exists(&split))
             {
-                /* the same filter on the half-precision matrix instruction where
-                 * that kernel fits (DRB_AMD_FAST_SPLIT=0, a diagnostic, keeps it off) */
-                Drb_Fast_Chain split = collapsed;
-                char const * const split_wish = getenv("DRB_AMD_FAST_SPLIT");
-
-                if (!(split_wish && atoi(split_wish) == 0) && drb_plan_split_geometry(&split, fast_lds_budget)
-                    && drb_hip_fast_kernel_exists(&split))
-                {
-                    launch->fast = split;
-                }
-                else if ((drb_hip_collapsed_shape(&collapsed), 1) && drb_hip_fast_kernel_exists(&collapsed)
-                         && (forced || drb_hip_collapsed_preferred(&collapsed)))
-                {
-                    launch->fast = collapsed;
-                }
+                launch->fast = split;
             }
         }
     }
@@ -400,12 +385,6 @@ static double issued_flops (Fast_Launch const * launches, int count, double * ha
         /* 16 x 16 x 4 products of 2048 flop each, per tile of one channel */
         long const up_blocks = fast->has_up ? (fast->seg_x + 15) / 16 : 0;
         long const down_blocks = fast->has_down ? (fast->seg_y + 15) / 16 : 0;
-        if (fast->kind == 3)
-        {
-            total += 2048.0 * (double)fast->blocks * fast->ksteps / (double)fast->tile_frames * launches[i].rate_ratio;
-            continue;
-        }
-
         if (fast->kind == 4)
         {
             /* four 16 x 16 x 32 products of 16384 flop per row block and step */
@@ -483,7 +462,7 @@ DrbAmd_Status drb_amd_plan_info (DrbAmd_Batch_Config const * config, DrbAmd_Plan
 
             if (i == 0 || launches[i].has_sinc)
             {
-                name = kind == 4 ? "drb_split_kernel" : kind == 3 ? "drb_collapsed_kernel" : kind == 2 ? "drb_interpolate_kernel"
+                name = kind == 4 ? "drb_split_kernel" : kind == 2 ? "drb_interpolate_kernel"
                      : kind == 1 ? "drb_decimate_kernel" : "drb_fast_kernel";
             }
         }
@@ -571,7 +550,6 @@ static void release (DrbAmd_Batch * batch)
     if (batch->collapse_jobs) drb_hip_free(batch->collapse_jobs);
     if (batch->collapse_spots) drb_hip_free(batch->collapse_spots);
     if (batch->collapse_sets) drb_hip_free(batch->collapse_sets);
-    if (batch->collapse_zeros) drb_hip_free(batch->collapse_zeros);
     free(batch->collapse_hash);
 
     if (batch->kernel_start) drb_hip_event_destroy(batch->kernel_start);
@@ -721,8 +699,6 @@ DrbAmd_Status drb_amd_batch_create (DrbAmd_Batch_Config const * config, DrbAmd_B
     /* the static workspace's address on this GPU (looked up once per device) */
     if (!code) code = drb_hip_static_workspace(device, &batch->static_base, &batch->static_bytes);
 
-    if (!code) code = drb_hip_alloc((void **)&batch->collapse_zeros, 256);
-    if (!code) code = drb_hip_memset_async(batch->collapse_zeros, 0, 256, 0);
     if (!code) code = drb_hip_memset_async(batch->fault_device, 0, fault_words * sizeof(long long), 0);
 
     if (code)
@@ -872,8 +848,7 @@ static DrbAmd_Status collapse_prepare
 
     Drb_Fast_Chain const * const fast = &launch->fast;
     int const n = batch->config.stream_count;
-    int const wanted = fast->rebuild_tiles > 0 ? fast->rebuild_tiles
-                     : fast->kind == 4 ? drb_split_stretch_tiles : drb_collapse_rebuild_tiles;
+    int const wanted = fast->rebuild_tiles > 0 ? fast->rebuild_tiles : drb_split_stretch_tiles;
     int max_stretches = 1, code;
     size_t total = 0;
 
@@ -1222,7 +1197,7 @@ DrbAmd_Status drb_amd_batch_process
                     shape, launch_calls, n, (int)((most[l] + fast_tile - 1) / fast_tile),
                     l == 0 ? history_in : launch->history[current], source_stride, target_stride,
                     batch->collapse_jobs, batch->collapse_spots, collapse_stretches, batch->collapse_sets,
-                    batch->collapse_zeros, batch->fault_device, hip_stream
+                    batch->fault_device, hip_stream
                 );
             }
             else code = drb_hip_launch_fast

@@ -85,15 +85,20 @@ typedef struct Drb_Fast_Chain
     int off_bank;                           /* sinc bank while coefficients are rebuilt: shares the planes of d where a down-sampler exists */
     int off_taps;                           /* half-band taps, zero-padded: up, then down */
     int kind;                               /* 0: [up] sinc [down]; 1: one half-band decimator on its own; 2: one interpolator;
-                                               3: [up] sinc [down] collapsed into one time-varying filter (see Drb_Collapse_Job);
-                                               4: the same filter with every float32 carried as two halves (see below) */
+                                               3: [up] sinc [down] collapsed into one time-varying filter (see Drb_Collapse_Job),
+                                                  a geometry only, on the way to
+                                               4: that filter with every float32 carried as two halves (see below) */
     int waves;                              /* waves per workgroup: 4 or 5, whichever deals the row blocks out more evenly */
     float column_drift;                     /* sub-sample position of segment c minus segment c - 1 (0: too small to matter) */
     int types_per_wave;                     /* row-block types one wave keeps coefficients for */
-    int plane_stride, plane_rows;           /* kind 3, planar float32: floats of a source plane in LDS (a straight copy of
-                                               the source, whole 256-frame loads), and rows one segment needs of it */
+    int plane_stride, plane_rows;           /* kinds 3, 4: source frames a tile is loaded as (whole 256-frame loads),
+                                               and rows one segment needs of them */
     int window;                             /* kinds 3, 4: source frames a row block's 16 target frames depend on, at most */
     int chunks;                             /* kind 4: 32-frame steps of a row block's window (3 or 4)                      */
+    int plane_words;                        /* kind 4: words of one channel's source plane in LDS                           */
+    int apart_stride;                       /* kind 4: 0: a plane is a straight copy of the source (odd segment lengths);
+                                               else every segment's rows have a stretch of their own, this many (an odd
+                                               number of) words apart                                                        */
     int lds_floats;
     int tile_frames;                        /* target frames per tile = 15 * seg_y    */
     long long source_delta, target_delta;
@@ -101,16 +106,16 @@ typedef struct Drb_Fast_Chain
 }
 Drb_Fast_Chain;
 
-/* Collapsed chains (kind 3).  [up2x] -> sinc -> [down2x] is one linear map from
+/* Collapsed chains (kinds 3, 4).  [up2x] -> sinc -> [down2x] is one linear map from
  * source frames to target frames whose rows repeat every period of the rate
  * ratio (up to the drift of the fixed-point phase), so a segment of seg_y
  * target frames is ONE banded product: `blocks` row blocks of 16 target frames,
  * each over a window of 4 * ksteps source frames.  The coefficients depend on
  * the phase only; a set is built on the device for every distinct phase the
  * host finds among the streams of a step ("job"), for an anchor segment in the
- * middle of a stretch of `rebuild_tiles` tiles, and every tile of the stretch
- * uses it, corrected to first order for the drift since the anchor. */
-enum { drb_collapse_max_blocks = 12, drb_collapse_rebuild_tiles = 8 /* tiles per stretch */ };
+ * middle of a stretch of tiles, and every tile of the stretch uses it,
+ * corrected to first order for the drift since the anchor. */
+enum { drb_collapse_max_blocks = 12 };
 
 /* Split chains (kind 4): the collapsed filter on v_mfma_f32_16x16x32_f16, which
  * runs at 16 times the rate of the float32 matrix instruction.  Every float32
@@ -118,7 +123,8 @@ enum { drb_collapse_max_blocks = 12, drb_collapse_rebuild_tiles = 8 /* tiles per
  * l = half((v - h) * 2048), and a product c x is accumulated in float32 as
  * ch xh + (ch xl + cl xh) / 2048; the dropped term cl xl is below 2^-22 |c x|.
  * A window is `chunks` steps of 32 source frames; a workgroup is one wave per
- * row block plus six that load.  The drift of the fixed-point phase is not
+ * row block plus six that load, and takes up to two channels of a stream
+ * through a tile (they share the phase, and with it the coefficients).  The drift of the fixed-point phase is not
  * folded into the coefficients: a fourth product with the coefficients'
  * derivatives is scaled per tile AND per segment by the distance from the
  * stretch's anchor, so a set serves a stretch of drb_split_stretch_tiles tiles
@@ -193,18 +199,10 @@ int drb_hip_launch_fast
         int * fault_flag, void * stream
     );
 
-/* Collapsed chains: coefficient sets for `job_count` jobs into `sets`
- * (collapse_set_words(chain) 32-bit words each), then the filter itself:
- * spots[stream * max_stretches + stretch]. */
+/* Split chains: coefficient sets for `job_count` jobs into `sets`
+ * (drb_hip_collapse_set_words(chain) 32-bit words each), then the filter
+ * itself: spots[stream * max_stretches + stretch]. */
 long long drb_hip_collapse_set_words (Drb_Fast_Chain const * chain);
-/* 1 where the collapsed kernel of this chain beats the staged one (measured:
- * planar float32 buffers, a tile's source in 12 wave-wide loads, and an odd
- * segment length, which keeps its operand reads free of LDS bank conflicts) */
-int drb_hip_collapsed_preferred (Drb_Fast_Chain const * chain);
-/* 32-bit words of one coefficient set of a kind 4 chain */
-long long drb_hip_split_set_words (Drb_Fast_Chain const * chain);
-/* settles how many waves filter (the kernel images that exist decide) */
-void drb_hip_collapsed_shape (Drb_Fast_Chain * chain);
 int drb_hip_launch_collapse_build
     (
         Drb_Fast_Chain const * chain, Drb_Collapse_Job const * jobs, int job_count,
@@ -217,7 +215,7 @@ int drb_hip_launch_collapsed
         float const * history,
         long long source_channel_stride, long long target_channel_stride,
         Drb_Collapse_Job const * jobs, Drb_Collapse_Spot const * spots, int max_stretches,
-        unsigned int const * sets, float const * zeros,
+        unsigned int const * sets,
         int * fault_flag, void * stream
     );
 

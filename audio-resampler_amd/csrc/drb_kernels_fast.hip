@@ -1973,41 +1973,14 @@ Fast_Kernel * pick_kernel (Drb_Fast_Chain const * chain)
 
 extern "C" int drb_hip_fast_kernel_exists (Drb_Fast_Chain const * chain)
 {
-    return chain->kind == 4 ? pick_split(chain) != nullptr
-         : chain->kind == 3 ? (collapsed_is_plain(chain) ? pick_collapsed_plain(chain) != nullptr : pick_collapsed(chain) != nullptr)
-                            : pick_kernel(chain) != nullptr;
-}
+    if (chain->kind == 3) return 0;   // a collapsed geometry before its split form is chosen: no kernel of its own
 
-// Planar float32 chains of nine or ten row blocks can run six filtering waves
-// (four with two blocks, two with one) instead of five with two each:
-// DRB_AMD_FAST_WAVES=6, a diagnostic.  Measured: 2 % less time on 44.1 -> 48 kHz
-// good (27 steps), 20 % more on best (31 steps), so five stay the rule.
-extern "C" void drb_hip_collapsed_shape (Drb_Fast_Chain * chain)
-{
-    char const * const wish = getenv("DRB_AMD_FAST_WAVES");
-
-    if (chain->kind == 3 && collapsed_is_plain(chain) && chain->waves == 5 && chain->types_per_wave == 2
-        && (chain->blocks == 9 || chain->blocks == 10) && wish && atoi(wish) == 6)
-    {
-        chain->waves = 6;
-    }
-}
-
-extern "C" int drb_hip_collapsed_preferred (Drb_Fast_Chain const * chain)
-{
-    // Measured: 44.1 -> 48 kHz good 0.38 against the staged kernel's 0.56 ms, best
-    // 0.45 against 0.60; but 48 -> 44.1 kHz 0.85 against 0.59.  There a segment
-    // is 160 source frames long, and since a plane is a straight copy of the
-    // source the 16 segments of an operand read lie 160 floats apart: all in one
-    // LDS bank.  An odd segment length spreads them over 16 banks.  (With 16
-    // loads per tile the workgroup also runs one to a CU instead of two.)
-    return chain->kind == 3 && collapsed_is_plain(chain) && pick_collapsed_plain(chain) != nullptr
-        && chain->plane_stride <= 12 * 256 && (chain->seg_x & 1);
+    return chain->kind == 4 ? pick_split(chain) != nullptr : pick_kernel(chain) != nullptr;
 }
 
 extern "C" long long drb_hip_collapse_set_words (Drb_Fast_Chain const * chain)
 {
-    return chain->kind == 4 ? split_set_words(chain->blocks, chain->chunks) : collapse_set_words(chain->blocks, chain->ksteps);
+    return split_set_words(chain->blocks, chain->chunks);
 }
 
 extern "C" int drb_hip_launch_collapse_build
@@ -2017,7 +1990,7 @@ extern "C" int drb_hip_launch_collapse_build
     )
 {
     if (job_count <= 0) return 0;
-    if ((chain->kind != 3 && chain->kind != 4) || chain->blocks < 1 || chain->blocks > drb_collapse_max_blocks) return hipErrorInvalidValue;
+    if (chain->kind != 4 || chain->blocks < 1 || chain->blocks > drb_split_max_blocks) return hipErrorInvalidValue;
 
     size_t const dynamic = static_cast<size_t>(kBuildOutputs) * (kBuildWide + 32) * sizeof(double);
 
@@ -2044,97 +2017,43 @@ extern "C" int drb_hip_launch_collapsed
         float const * history,
         long long source_channel_stride, long long target_channel_stride,
         Drb_Collapse_Job const * jobs, Drb_Collapse_Spot const * spots, int max_stretches,
-        unsigned int const * sets, float const * zeros,
+        unsigned int const * sets,
         int * fault_flag, void * stream
     )
 {
     if (stream_count <= 0 || max_tiles <= 0) return 0;
 
-    if (chain->kind == 4)
+    if (chain->kind != 4) return hipErrorInvalidValue;
+
+    Split_Kernel * const split = pick_split(chain);
+
+    if (!split || max_stretches < 1) return hipErrorInvalidValue;
+
+    size_t const bytes = static_cast<size_t>(chain->lds_floats) * sizeof(unsigned);
+
+    if (bytes > 48 * 1024)
     {
-        Split_Kernel * const split = pick_split(chain);
-
-        if (!split || max_stretches < 1) return hipErrorInvalidValue;
-
-        size_t const bytes = static_cast<size_t>(chain->lds_floats) * sizeof(unsigned);
-
-        if (bytes > 48 * 1024)
-        {
-            hipError_t const status = hipFuncSetAttribute(reinterpret_cast<void const *>(split),
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
-
-            if (status != hipSuccess) return status;
-        }
-
-        // one workgroup fills a CU; a workgroup walks over the tiles of its stream
-        // and channel with a stride, a few workgroups per CU in all
-        long long const pairs = static_cast<long long>(stream_count) * chain->channels;
-        long long stride = (1024 + pairs - 1) / pairs;
-
-        if (chain->tile_stride > 0) stride = chain->tile_stride;
-        if (stride > max_tiles) stride = max_tiles;
-        if (stride < 1) stride = 1;
-        if (pairs * stride > 0x7fffffffLL) return hipErrorInvalidValue;
-
-        split<<<dim3(static_cast<unsigned>(pairs * stride)), dim3(static_cast<unsigned>(64 * (chain->blocks + kSplitLoaders))), bytes, static_cast<hipStream_t>(stream)>>>
-        (
-            *chain, calls, stream_count, static_cast<int>(stride), history,
-            source_channel_stride, target_channel_stride, jobs, spots, max_stretches, sets, fault_flag
-        );
-
-        return hipGetLastError();
-    }
-
-    bool const plain = collapsed_is_plain(chain);
-    Collapsed_Kernel * const kernel = plain ? nullptr : pick_collapsed(chain);
-    Collapsed_Plain_Kernel * const plain_kernel = plain ? pick_collapsed_plain(chain) : nullptr;
-
-    if ((!kernel && !plain_kernel) || max_stretches < 1 || (plain && !zeros)) return hipErrorInvalidValue;
-
-    // (planar float32: every filtering wave parks its coefficients' slopes behind the planes)
-    size_t const dynamic = static_cast<size_t>(chain->lds_floats) * sizeof(float)
-        + (plain ? static_cast<size_t>(chain->waves) * chain->types_per_wave * ((chain->ksteps + 1) / 2) * 64 * sizeof(unsigned) : 0);
-
-    if (dynamic > 48 * 1024)
-    {
-        hipError_t const status = hipFuncSetAttribute
-        (
-            plain ? reinterpret_cast<void const *>(plain_kernel) : reinterpret_cast<void const *>(kernel),
-            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(dynamic)
-        );
+        hipError_t const status = hipFuncSetAttribute(reinterpret_cast<void const *>(split),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
 
         if (status != hipSuccess) return status;
     }
 
-    // a workgroup walks over the tiles of its stream and channel with a stride;
-    // about eight workgroups per CU keep the chip busy
-    long long const pairs = static_cast<long long>(stream_count) * chain->channels;
-    long long tile_stride = (2048 + pairs - 1) / pairs;
+    // one workgroup fills a CU; a workgroup walks over the tiles of its stream
+    // and channel (or channel pair) with a stride, a few workgroups per CU in all
+    long long const pairs = static_cast<long long>(stream_count) * (chain->layout == kInterleaved && chain->channels == 2 ? 1 : chain->channels);
+    long long stride = (1024 + pairs - 1) / pairs;
 
-    if (chain->tile_stride > 0) tile_stride = chain->tile_stride;
-    if (tile_stride > max_tiles) tile_stride = max_tiles;
-    if (tile_stride < 1) tile_stride = 1;
+    if (chain->tile_stride > 0) stride = chain->tile_stride;
+    if (stride > max_tiles) stride = max_tiles;
+    if (stride < 1) stride = 1;
+    if (pairs * stride > 0x7fffffffLL) return hipErrorInvalidValue;
 
-    long long const blocks = pairs * tile_stride;
-
-    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-
-    if (plain)
-    {
-        plain_kernel<<<dim3(static_cast<unsigned>(blocks)), dim3(static_cast<unsigned>(64 * (chain->waves + 1))), dynamic, static_cast<hipStream_t>(stream)>>>
-        (
-            *chain, calls, stream_count, static_cast<int>(tile_stride), history,
-            source_channel_stride, target_channel_stride, jobs, spots, max_stretches, sets, zeros, fault_flag
-        );
-    }
-    else
-    {
-        kernel<<<dim3(static_cast<unsigned>(blocks)), dim3(static_cast<unsigned>(64 * chain->waves)), dynamic, static_cast<hipStream_t>(stream)>>>
-        (
-            *chain, calls, stream_count, static_cast<int>(tile_stride), history,
-            source_channel_stride, target_channel_stride, jobs, spots, max_stretches, sets, fault_flag
-        );
-    }
+    split<<<dim3(static_cast<unsigned>(pairs * stride)), dim3(static_cast<unsigned>(64 * (chain->blocks + kSplitLoaders))), bytes, static_cast<hipStream_t>(stream)>>>
+    (
+        *chain, calls, stream_count, static_cast<int>(stride), history,
+        source_channel_stride, target_channel_stride, jobs, spots, max_stretches, sets, fault_flag
+    );
 
     return hipGetLastError();
 }

@@ -955,11 +955,11 @@ static void collapse_extents (Drb_Fast_Chain const * chain, long long rest, int 
     }
 }
 
-int drb_plan_collapse_geometry (Drb_Fast_Chain * chain, int lds_budget_bytes)
+int drb_plan_collapse_geometry (Drb_Fast_Chain * chain, int lds_budget_bytes, int drifting_columns)
 {
     if (!chain->usable || chain->kind != 0) return 0;
     if (!chain->has_up && !chain->has_down) return 0;   /* one stage: nothing to collapse */
-    if (chain->column_drift != 0.0f) return 0;
+    if (chain->column_drift != 0.0f && !drifting_columns) return 0;
 
     Drb_Fast_Chain c = *chain;
 
@@ -1048,19 +1048,18 @@ int drb_plan_split_geometry (Drb_Fast_Chain * chain, int lds_budget_bytes)
     if (c.chunks < 3) c.chunks = 3;
     if (c.chunks > 4 || c.blocks > drb_split_max_blocks) return 0;
 
-    /* Segments lie seg_x words apart in a plane, and the 16 columns of an operand
-     * read must fall into 16 different LDS banks: an odd distance does that. */
-    if (!(c.seg_x & 1)) return 0;
-
     c.kind = 4;
     c.ksteps = 8 * c.chunks;          /* a window is 4 * ksteps rows, as for kind 3 */
     c.waves = c.blocks;
     c.types_per_wave = 1;
+    c.column_drift = 0.0f;            /* (every segment gets its own phase anyway) */
 
     /* a window may not start behind the row that leaves it whole inside the segment's rows */
     while (c.seg_x + c.look_x + 8 - 4 * c.ksteps < 0) c.look_x += 4;
 
     c.plane_rows = (c.seg_x + c.look_x + 8 + 3) / 4 * 4;
+
+    if (c.plane_rows > 2 * c.seg_x) return 0;   /* a source frame lies in two segments' rows at most */
 
     int const reach = 15 * c.seg_x + c.plane_rows + 31;
 
@@ -1068,8 +1067,28 @@ int drb_plan_split_geometry (Drb_Fast_Chain * chain, int lds_budget_bytes)
 
     if (!c.plane_stride) return 0;
 
+    /* The 16 columns of an operand read must fall into 16 different LDS banks: they
+     * do where the segments lie an odd number of words apart.  A straight copy of
+     * the source has them seg_x apart; for even seg_x every segment's rows get a
+     * stretch of their own instead, an odd number of words from the next. */
+    if (c.seg_x & 1)
+    {
+        c.apart_stride = 0;
+        c.plane_words = c.plane_stride;
+    }
+    else
+    {
+        c.apart_stride = (c.plane_rows + 4) | 1;
+        c.plane_words = 16 * c.apart_stride;
+    }
+
+    /* planes [3][channels of a workgroup], then two images [channels] of a tile's
+     * target frames; a workgroup takes both channels of an interleaved stereo
+     * stream, else one channel */
+    int const together = c.layout == 1 && c.channels == 2 ? 2 : 1;
+
     c.off_x = 0;
-    c.lds_floats = drb_split_planes * c.plane_stride + 2 * 16 * c.seg_y;   /* planes, then two images of a tile's target frames */
+    c.lds_floats = drb_split_planes * together * c.plane_words + 2 * together * 16 * c.seg_y;
 
     if (c.lds_floats * 4 > lds_budget_bytes) return 0;
 

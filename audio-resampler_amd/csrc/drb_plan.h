@@ -138,8 +138,10 @@ int drb_plan_fast_geometry (Drb_Plan const * plan, int lds_budget_bytes, struct 
 
 /* Turns a usable [up] sinc [down] geometry into the collapsed form (kind 3: one
  * banded product per segment, see drb_hip.h); returns 0 and leaves the chain
- * alone where that form does not apply. */
-int drb_plan_collapse_geometry (struct Drb_Fast_Chain * chain, int lds_budget_bytes);
+ * alone where that form does not apply.  drifting_columns: also where the
+ * phase differs noticeably from segment to segment (kind 4 gives every segment
+ * its own; kind 3 does not). */
+int drb_plan_collapse_geometry (struct Drb_Fast_Chain * chain, int lds_budget_bytes, int drifting_columns);
 
 /* Turns a collapsed geometry (kind 3) into the split form (kind 4: the same
  * filter on the half-precision matrix instruction, see drb_hip.h); returns 0

@@ -83,16 +83,16 @@ def test_fast_mode_within_tolerance_of_golden(name):
         runner.close()
 
 
-@pytest.mark.parametrize("stride,collapsed", [("", "0"), ("1", "0"), ("", "1")])
-def test_fast_mode_long_stream_many_tiles(stride, collapsed, monkeypatch):
+@pytest.mark.parametrize("stride,split", [("", "0"), ("1", "0"), ("", "1"), ("1", "1")])
+def test_fast_mode_long_stream_many_tiles(stride, split, monkeypatch):
     """Several tiles per step and several steps: 4 s of noise and of sweep; with
     the launcher's choice of how workgroups share a stream's tiles and with one
     workgroup walking over all of them (which hands each tile's tail on to the
     next instead of warming every tile up); with the three stages kept apart and
-    collapsed into one filter."""
+    as one filter on the half-precision matrix instruction."""
     if stride:
         monkeypatch.setenv("DRB_AMD_FAST_TILE_STRIDE", stride)
-    monkeypatch.setenv("DRB_AMD_FAST_COLLAPSED", collapsed)
+    monkeypatch.setenv("DRB_AMD_FAST_SPLIT", split)
     for signal in ("noise", "sweep"):
         ch, frames = 2, 4 * 44100
         x = support.white_noise(ch, frames, 21) if signal == "noise" else support.log_sweep(ch, frames, 44100, 0.45 * 44100)
@@ -108,8 +108,8 @@ def test_fast_mode_long_stream_many_tiles(stride, collapsed, monkeypatch):
             assert got.shape == want.shape
             worst = assert_close(got, want, "%s stream %d" % (signal, s))
             # staged: 4.8e-7 with coefficients rebuilt for every tile, 7.2e-7 following the
-            # drift over 16; collapsed: 9.5e-7 (one sum of ~100 products per frame)
-            assert worst < (1.1e-6 if collapsed == "1" else 8e-7)
+            # drift over 16; split: 9.5e-7 (one sum of ~100 products per frame)
+            assert worst < (1.1e-6 if split == "1" else 8e-7)
         runner.close()
 
 

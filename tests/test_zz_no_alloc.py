@@ -20,7 +20,7 @@ drbamd = pytest.importorskip("drbamd")
 
 CASES = [
     ("exact", drbamd.EXACT, 44100, 48000, 2, support.GOOD, 5),
-    ("fast, collapsed matrix-core kernel", drbamd.FAST, 44100, 48000, 2, support.GOOD, 6),
+    ("fast, split matrix-core kernel", drbamd.FAST, 44100, 48000, 2, support.GOOD, 6),
     ("fast, one decimator", drbamd.FAST, 96000, 48000, 8, support.GOOD, 3),
 ]
 

@@ -20,13 +20,22 @@ LOADER = ["wait for loads", "convert", "issue", "barrier+idle"]
 
 
 def main():
-    streams, ch, frames = 1024, 2, int(os.environ.get("STAMP_FRAMES", "441088"))
-    config = drbamd.make_config(44100, 48000, ch, 256, 16, drbamd.PUSH, drbamd.GOOD,
+    streams, ch = 1024, 2
+    cfg2 = os.environ.get("STAMP_CONFIG", "headline") == "cfg2"
+    src_rate, dst_rate = (48000, 44100) if cfg2 else (44100, 48000)
+    frames = int(os.environ.get("STAMP_FRAMES", str(10 * src_rate // 256 * 256)))
+    config = drbamd.make_config(src_rate, dst_rate, ch, 256, 16, drbamd.PUSH, drbamd.GOOD,
+                                sample_type=drbamd.I16 if cfg2 else drbamd.F32,
+                                layout=drbamd.INTERLEAVED if cfg2 else drbamd.PLANAR,
                                 arithmetic=drbamd.FAST, streams=streams)
     batch = drbamd.Batch(config)
     cap = batch.query([frames] * streams)[0] + 4096
-    src = torch.rand((streams, ch, frames + 4096), device="cuda") * 2 - 1
-    dst = torch.zeros((streams, ch, cap), device="cuda")
+    if cfg2:
+        src = (torch.rand((streams, frames + 4096, ch), device="cuda") * 65000 - 32500).to(torch.int16)
+        dst = torch.zeros((streams, cap, ch), device="cuda", dtype=torch.int16)
+    else:
+        src = torch.rand((streams, ch, frames + 4096), device="cuda") * 2 - 1
+        dst = torch.zeros((streams, ch, cap), device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     counters = (ctypes.c_ulonglong * 96)()
     drbamd.lib.drb_amd_debug_counters.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
@@ -35,7 +44,8 @@ def main():
                             frames, cap, stream=stream)
         batch.synchronize(stream)
         drbamd.check(drbamd.lib.drb_amd_debug_counters(batch.handle, counters, 96))
-    tiles = streams * ch * ((frames * 160 // 147 + 2559) // 2560)
+    tile = 16 * 147 if cfg2 else 2560
+    tiles = streams * ch * ((frames * dst_rate // src_rate + tile - 1) // tile)
     blocks, loaders = 10, 6
     row = [counters[p] / blocks for p in range(4)]
     print("a filtering wave, %6.0f cycles per tile:  " % (sum(row) / tiles)
