@@ -45,7 +45,8 @@ def main():
         batch.synchronize(stream)
         drbamd.check(drbamd.lib.drb_amd_debug_counters(batch.handle, counters, 96))
     tile = 16 * 147 if cfg2 else 2560
-    tiles = streams * ch * ((frames * dst_rate // src_rate + tile - 1) // tile)
+    groups = 1 if cfg2 else ch   # interleaved stereo: one workgroup takes both channels through a tile
+    tiles = streams * groups * ((frames * dst_rate // src_rate + tile - 1) // tile)
     blocks, loaders = 10, 6
     row = [counters[p] / blocks for p in range(4)]
     print("a filtering wave, %6.0f cycles per tile:  " % (sum(row) / tiles)
@@ -53,9 +54,9 @@ def main():
     row = [counters[16 + p] / loaders for p in range(4)]
     print("a loader,         %6.0f cycles per tile:  " % (sum(row) / tiles)
           + "  ".join("%s %.0f" % (LOADER[p], row[p] / tiles) for p in range(4))
-          + "  (it converts half of every third tile)")
+          + ("  (it converts a third of every second tile)" if cfg2 else "  (it converts half of every third tile)"))
     if counters[9]:
-        life, real = counters[8] / (streams * ch), counters[9] / (streams * ch)
+        life, real = counters[8] / (streams * groups), counters[9] / (streams * groups)
         print("workgroup lifetime %.0f cycles = %.2f us: shader clock %.2f GHz" % (life, real / 100.0, life / real * 0.1))
 
 
