@@ -15,7 +15,7 @@ fi
 timeout -k 10 300 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || { tail -20 $OUT/bench.err; exit 1; }
 cat $OUT/bench.json
 export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-host-fed"
+BENCH="python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-host-fed --no-configs"
 mkdir -p $OUT/trace
 cd /tmp
 timeout -s KILL 180 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- $BENCH > $OUT/trace/bench.log 2> $OUT/trace.err || { tail -20 $OUT/trace.err; exit 1; }
