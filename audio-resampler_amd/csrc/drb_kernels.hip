@@ -50,16 +50,26 @@ __device__ inline int floor_half (int v) { return v >> 1; }
 
 // ---- sample load / store with type conversion ------------------------------
 
+// (the callers' buffers are device memory: pointers that say so become global
+// instead of flat loads and stores)
+#define DRB_GLOBAL __attribute__((address_space(1)))
+
+template <typename T>
+__device__ __forceinline__ DRB_GLOBAL T * global_pointer (void const * address)
+{
+    return reinterpret_cast<DRB_GLOBAL T *>(reinterpret_cast<unsigned long long>(address));
+}
+
 __device__ inline float load_sample (void const * base, long long index, int type)
 {
     switch (type)
     {
       case kSampleI16:
-        return static_cast<float>(static_cast<short const *>(base)[index]) * (1.0f / 32768.0f);
+        return static_cast<float>(global_pointer<short const>(base)[index]) * (1.0f / 32768.0f);
       case kSampleI32:
-        return static_cast<float>(static_cast<int const *>(base)[index]) * (1.0f / 2147483648.0f);
+        return static_cast<float>(global_pointer<int const>(base)[index]) * (1.0f / 2147483648.0f);
       default:
-        return static_cast<float const *>(base)[index];
+        return global_pointer<float const>(base)[index];
     }
 }
 
@@ -73,7 +83,7 @@ __device__ inline void store_sample (void * base, long long index, int type, flo
         int const q = scaled >= 32767.0f ? 32767
                     : scaled <= -32768.0f ? -32768
                     : scaled != scaled ? 0 : static_cast<int>(scaled);
-        static_cast<short *>(base)[index] = static_cast<short>(q);
+        global_pointer<short>(base)[index] = static_cast<short>(q);
         break;
       }
       case kSampleI32:
@@ -82,11 +92,11 @@ __device__ inline void store_sample (void * base, long long index, int type, flo
         int const q = scaled >= 2147483648.0f ? 2147483647
                     : scaled <= -2147483648.0f ? (-2147483647 - 1)
                     : scaled != scaled ? 0 : static_cast<int>(scaled);
-        static_cast<int *>(base)[index] = q;
+        global_pointer<int>(base)[index] = q;
         break;
       }
       default:
-        static_cast<float *>(base)[index] = value;
+        global_pointer<float>(base)[index] = value;
     }
 }
 
@@ -431,8 +441,10 @@ __global__ __launch_bounds__(kThreads) void drb_cascade_kernel
     int const width = chain.lds_width;
     int const channels = chain.channels;
 
-    float * const buffers [2] = { lds, lds + channels * width };
-    float * const bank = lds + 2 * channels * width;
+    // (offsets from the one LDS array, not an array of pointers: the compiler then
+    // keeps every access an LDS instruction instead of a flat one)
+    int const buffer_floats = channels * width;
+    float * const bank = lds + 2 * buffer_floats;
     Ranges & ranges = *reinterpret_cast<Ranges *>(bank + bank_floats);
 
     // -- backwards: index range needed on every edge --------------------------
@@ -524,7 +536,7 @@ __global__ __launch_bounds__(kThreads) void drb_cascade_kernel
                 int const position = i / channels, channel = i - position * channels;
                 float const v = source_frame(chain, call, stream_history, source_channel_stride,
                                              channel, lo + position - shift);
-                put(buffers[0] + channel * width, width, split, position, v);
+                put(lds + channel * width, width, split, position, v);
             }
         }
         else
@@ -535,7 +547,7 @@ __global__ __launch_bounds__(kThreads) void drb_cascade_kernel
                 {
                     float const v = source_frame(chain, call, stream_history, source_channel_stride,
                                                  channel, lo + position - shift);
-                    put(buffers[0] + channel * width, width, split, position, v);
+                    put(lds + channel * width, width, split, position, v);
                 }
             }
         }
@@ -547,8 +559,8 @@ __global__ __launch_bounds__(kThreads) void drb_cascade_kernel
     for (int k = 0; k < stages; k++)
     {
         Drb_Device_Stage const stage = chain.stages[k];
-        float const * const in = buffers[k & 1];
-        float * const out = buffers[(k + 1) & 1];
+        float const * const in = lds + (k & 1) * buffer_floats;
+        float * const out = lds + ((k + 1) & 1) * buffer_floats;
         int const shift = chain.delay_edge == k + 1 ? call.delay : 0;
         int const lo = ranges.lo[k + 1] - shift, hi = ranges.hi[k + 1] - shift;
         int const out_split = k + 1 < stages && chain.stages[k + 1].kind == kStageDown2x;
@@ -589,7 +601,7 @@ __global__ __launch_bounds__(kThreads) void drb_cascade_kernel
 
     // -- store the tile ----------------------------------------------------------
     {
-        float const * const result = buffers[stages & 1];
+        float const * const result = lds + (stages & 1) * buffer_floats;
         int const count = last - first;
         void * const target = reinterpret_cast<void *>(call.target);
 
