@@ -256,6 +256,8 @@ static int build_launches (DrbAmd_Batch_Config const * config, Drb_Plan const * 
      * float32 bit for bit.  Only the exact kernels deliver that: fast arithmetic
      * on int32 buffers runs them. */
     if (config->sample_type == drb_amd_sample_i32) return 0;
+    if (config->arithmetic != drb_amd_arithmetic_fast) return 0;
+
     int first [max_launches], last [max_launches];
 
     for (int k = 0; k < plan->stage_count; k++) if (plan->stages[k].kind == drb_stage_sinc) sinc = k;

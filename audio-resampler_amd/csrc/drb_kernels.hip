@@ -24,7 +24,7 @@
 namespace
 {
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 512;
 
 enum { kStageUp2x = 1, kStageDown2x = 2, kStageSinc = 3 };
 enum { kSampleF32 = 0, kSampleI16 = 1, kSampleI32 = 2 };
@@ -42,6 +42,8 @@ __device__ inline float const * table_at (int float_offset)
 }
 
 // One rounding per operation, whatever the contraction flags say.
+typedef float float2_t __attribute__((ext_vector_type(2)));
+
 __device__ inline float mul (float a, float b) { return __fmul_rn(a, b); }
 __device__ inline float add (float a, float b) { return __fadd_rn(a, b); }
 __device__ inline float mac (float acc, float a, float b) { return __fadd_rn(acc, __fmul_rn(a, b)); }
@@ -333,24 +335,31 @@ __device__ void stage_sinc
             float const * const a = in + channel * width + start;
             float const * const b = pair ? a + width : a;
 
-            float pa [kRows], pb [kRows];
+            // Two channels side by side in packed registers: one v_pk_mul_f32 and one
+            // v_pk_add_f32 per tap and row, each half rounded as the scalar
+            // instructions round, in the same order.
+            float2_t p [kRows];
 
             #pragma unroll
-            for (int r = 0; r < kRows; r++) { pa[r] = 0.0f; pb[r] = 0.0f; }
+            for (int r = 0; r < kRows; r++) p[r] = float2_t{ 0.0f, 0.0f };
 
             #pragma unroll
             for (int t = 0; t < TAPS; t++)
             {
-                float const xa = a[t], xb = b[t];
+                float2_t const x = { a[t], b[t] };
 
                 #pragma unroll
                 for (int r = 0; r < kRows; r++)
                 {
                     float const k = rows[r * kStride + t];
-                    pa[r] = mac(pa[r], k, xa);
-                    pb[r] = mac(pb[r], k, xb);
+                    p[r] = p[r] + x * float2_t{ k, k };
                 }
             }
+
+            float pa [kRows], pb [kRows];
+
+            #pragma unroll
+            for (int r = 0; r < kRows; r++) { pa[r] = p[r][0]; pb[r] = p[r][1]; }
 
             float ya, yb;
 

@@ -115,9 +115,11 @@ def host_fed(batch, source, ch, target_capacity, torch_type, frames, capacity, l
     import torch
 
     streams = source.shape[0]
-    host_source = source.cpu().pin_memory()
+    # pinned from the start: a pageable copy on the way would take the memory next to the GPU
+    host_source = torch.empty(source.shape, dtype=source.dtype, pin_memory=True)
+    host_source.copy_(source)
     source_frames = host_source.shape[2] if layout == "planar" else host_source.shape[1]
-    host_target = torch.zeros(streams * ch * target_capacity, dtype=torch_type).pin_memory()
+    host_target = torch.zeros(streams * ch * target_capacity, dtype=torch_type, pin_memory=True)
     produced = (ctypes.c_int * streams)()
 
     def step():
@@ -179,7 +181,7 @@ def roofline_of(info, fast, samples_per_launch, kernel_ms, step_ms):
 
 
 def measure(name, arithmetic, streams, seconds, steps, warmup, rank, world, local_rank,
-            call_frames=0, ragged=None, phases_apart=False, want_host_fed=False, kernel_probe=6):
+            call_frames=0, ragged=None, phases_apart=False, want_host_fed=False, kernel_probe=6, host_fed_seconds=1.0):
     """Runs one workload on this rank's GPU and returns its measurements.  The
     timed region is bracketed by barriers over all ranks and device
     synchronisation on both sides; the time is the slowest rank's."""
@@ -371,14 +373,14 @@ def measure(name, arithmetic, streams, seconds, steps, warmup, rank, world, loca
 
     if want_host_fed:
         # one second per stream per call, whatever the step above was (1.5 GB of pinned memory instead of 15)
-        fed = int(round(min(seconds, 1.0) * user_rate / bs)) * bs
+        fed = int(round(min(seconds, host_fed_seconds) * user_rate / bs)) * bs
         fed_other = batch.query([fed] * streams)[0]
         fed_source = fed_other + 4096 if direction == 1 else fed
         fed_target = fed if direction == 1 else fed_other + 4096
         fed_slice = source[:, :fed_source, :] if layout == "interleaved" else source[:, :, :fed_source]
         result["host_fed"] = host_fed(batch, fed_slice.contiguous(), ch, fed_target, torch_type, fed,
                                       fed_source if direction == 1 else fed_target, layout, direction)
-        result["host_fed"]["seconds_per_step"] = min(seconds, 1.0)
+        result["host_fed"]["seconds_per_step"] = min(seconds, host_fed_seconds)
 
     batch.close()
     del source, target
@@ -414,6 +416,8 @@ def main():
     parser.add_argument("--arithmetic", default="fast", choices=["exact", "fast"])
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--no-host-fed", action="store_true", help="skip the PCIe-inclusive side measurement")
+    parser.add_argument("--host-fed-seconds", type=float, default=1.0,
+                        help="seconds per stream per call of the PCIe-inclusive side measurement (pinned memory grows with it)")
     parser.add_argument("--no-configs", action="store_true", help="skip the other configurations and headline variants")
     args = parser.parse_args()
 
@@ -440,7 +444,7 @@ def main():
     single = world == 1
     main_run = measure(args.workload, args.arithmetic, streams, args.seconds, args.steps, args.warmup, rank, world, local_rank,
                        call_frames=args.call_frames, phases_apart=args.phases_apart,
-                       want_host_fed=single and not args.no_host_fed)
+                       want_host_fed=single and not args.no_host_fed, host_fed_seconds=args.host_fed_seconds)
 
     if rank == 0:
         src, dst = WORKLOADS[args.workload][:2]
