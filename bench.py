@@ -402,8 +402,9 @@ def traffic_of(name, arithmetic, streams, seconds):
 def main():
     parser = argparse.ArgumentParser()
     parser.add_argument("--gpus", type=int, default=1)
-    parser.add_argument("--steps", type=int, default=20)
-    parser.add_argument("--warmup", type=int, default=3)
+    parser.add_argument("--steps", type=int, default=50)
+    parser.add_argument("--warmup", type=int, default=20,
+                        help="untimed steps first (the clocks take some 15 launches to settle after an idle spell)")
     parser.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
     parser.add_argument("--streams", type=int, default=0, help="streams per GPU (0 = workload default)")
     parser.add_argument("--scaling", default="weak", choices=["weak", "strong"])
@@ -467,9 +468,9 @@ def main():
     if single and not args.no_configs and args.workload == "headline" and not args.call_frames and not args.phases_apart:
         configs = []
         for label, name, options in SIDE_RUNS:
-            side_steps = 3 if options.get("call_frames") else 5
+            side_steps = 3 if options.get("call_frames") else 10
             try:
-                run = measure(name, args.arithmetic, WORKLOADS[name][9], 10.0, side_steps, 1, rank, world, local_rank, **options)
+                run = measure(name, args.arithmetic, WORKLOADS[name][9], 10.0, side_steps, 1 if options.get("call_frames") else 4, rank, world, local_rank, **options)
             except Exception as error:  # a side measurement never takes the headline down with it
                 configs.append({"name": label, "error": "%s: %s" % (type(error).__name__, error)})
                 continue

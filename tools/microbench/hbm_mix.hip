@@ -62,6 +62,24 @@ __global__ __launch_bounds__(1024) void copy_tiles (float const * __restrict__ i
     }
 }
 
+// the same with twice as much read as written: tiles of 5120 floats in, 2560 out
+__global__ __launch_bounds__(1024) void copy_tiles_2to1 (float const * __restrict__ in, float * __restrict__ out, int rows, int tiles, int stride, long long in_row, long long out_row)
+{
+    int const row = blockIdx.x % rows;
+    float const * const from = in + row * in_row;
+    float * const to = out + row * out_row;
+    int const lane = threadIdx.x;
+
+    for (int tile = blockIdx.x / rows; tile < tiles; tile += stride)
+    {
+        float4_t a = *reinterpret_cast<float4_t const *>(from + 5120LL * tile + 4 * lane);
+        float4_t b = { 0, 0, 0, 0 };
+
+        if (lane < 256) b = *reinterpret_cast<float4_t const *>(from + 5120LL * tile + 4096 + 4 * lane);
+        if (lane < 640) *reinterpret_cast<float4_t *>(to + 2560LL * tile + 4 * lane) = a + b;
+    }
+}
+
 int main ()
 {
     long long const in_bytes = 3640000000LL / 16 * 16, out_bytes = 3940000000LL / 16 * 16;
@@ -132,6 +150,20 @@ int main ()
             timed(name, 4.0 * rows * tiles * (2352.0 + 2560.0),
                   [&] { copy_tiles<<<grid, 1024>>>(in, out, rows, tiles, stride, in_row, out_row); });
         }
+    }
+
+    // a half-band decimator's pattern: 4096 x 8 rows of 960 000 frames in and 480 000 out
+    // would be 31 GB; a tenth of it here: rows of 96 000 in (tiles of 5120) and 48 000 out (2560)
+    {
+        int const rows = 8192, tiles = 18;   // 8192 x 98 048 x 4 B = 3.2 GB in, 1.6 GB out: inside both buffers
+        long long const in_row = 96000 + 2048, out_row = 48000 + 1024;
+
+        // (3.2 GB + 1.6 GB: fits the two buffers)
+        snprintf(name, sizeof(name), "2:1 tiles, %d workgroups x 1024", rows);
+        timed(name, 4.0 * rows * tiles * (5120.0 + 2560.0), [&]
+        {
+            copy_tiles_2to1<<<rows, 1024>>>(in, out, rows, tiles, 1, in_row, out_row);
+        });
     }
 
     return 0;

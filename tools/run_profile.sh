@@ -15,7 +15,7 @@ fi
 timeout -k 10 300 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || { tail -20 $OUT/bench.err; exit 1; }
 cat $OUT/bench.json
 export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-host-fed --no-configs"
+BENCH="python3 $ROOT/bench.py --steps 20 --warmup 15 --no-cpu-baseline --no-host-fed --no-configs"
 mkdir -p $OUT/trace
 cd /tmp
 timeout -s KILL 180 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- $BENCH > $OUT/trace/bench.log 2> $OUT/trace.err || { tail -20 $OUT/trace.err; exit 1; }
@@ -29,3 +29,19 @@ done
 cd $ROOT
 for d in $OUT/pmc_*/; do python3 tools/pmc_summary.py $d drb_; done > $OUT/pmc_summary.txt
 cat $OUT/pmc_summary.txt
+python3 - $OUT <<'PY' > $OUT/dispatches.txt
+import csv, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1] + "/trace/trace_kernel_trace.csv"))]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+names = {}
+for r in rows:
+    name = r["Kernel_Name"]
+    if "drb_" not in name: continue
+    short = name[name.find("drb_"):].split("(")[0]
+    names.setdefault(short, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+for short, times in names.items():
+    last = times[-20:]
+    print("%s: %d dispatches; ms in order: %s" % (short, len(times), " ".join("%.3f" % t for t in times)))
+    print("%s: mean of the last %d (the timed steps): %.4f ms; of all: %.4f ms" % (short, len(last), sum(last) / len(last), sum(times) / len(times)))
+PY
+cat $OUT/dispatches.txt | cut -c1-400
