@@ -1144,6 +1144,22 @@ DrbAmd_Status drb_amd_batch_process
 
             if (limit && atoi(limit) == 1 && batch->launches[l].has_staged) { apart[l] = 1; continue; }
 
+            /* A step of a tile or two per stream (calls of a few thousand frames) is all
+             * set-up: the staged kernels need no coefficient sets built and uploaded
+             * first, and their small workgroups overlap on a CU where the split
+             * kernel's one workgroup per CU starts and drains alone.  Measured on
+             * 4096-frame calls of 1024 streams: 0.117 against 0.141 ms of device time
+             * per call, 0.108 against 0.157 ms of host time. */
+            if (batch->launches[l].has_staged && !(limit && atoi(limit) == 0))
+            {
+                Drb_Device_Call const * const row = calls + (size_t)l * n;
+                long long most_frames = 0;
+
+                for (int s = 0; s < n; s++) if (row[s].target_frames > most_frames) most_frames = row[s].target_frames;
+
+                if (most_frames <= 2LL * batch->launches[l].fast.tile_frames) { apart[l] = 1; continue; }
+            }
+
             DrbAmd_Status const status = collapse_prepare(batch, &batch->launches[l], calls + (size_t)l * n, slot, hip_stream,
                                                           &collapse_stretches, &collapse_job_count, &apart[l]);
 
