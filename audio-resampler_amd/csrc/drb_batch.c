@@ -247,6 +247,8 @@ enum { lds_budget = 56 * 1024, fast_lds_budget = 78 * 1024, split_lds_budget = 1
  * stage are 2x stages only, one launch each (the slicer with the last
  * up-sampler or the first down-sampler).  Returns the number of launches, 0 if
  * some launch has no kernel (fast arithmetic then runs the cascade kernel). */
+static int make_launches (DrbAmd_Batch_Config const * config, Drb_Plan const * plan, int const * first, int const * last, int count, Fast_Launch * launches);
+
 static int build_launches (DrbAmd_Batch_Config const * config, Drb_Plan const * plan, Fast_Launch * launches)
 {
     int sinc = -1, count = 0;
@@ -298,6 +300,41 @@ static int build_launches (DrbAmd_Batch_Config const * config, Drb_Plan const * 
 
     if (count < 1 || count > max_launches) return 0;
 
+    /* Interpolators in front of the sinc stage's launch: folded into its filter where
+     * the split kernel takes the longer chain (the rates in between then never
+     * reach memory), else launches of their own. */
+    if (sinc >= 0)
+    {
+        int core = -1, lone_ups = 1;
+
+        for (int i = 0; i < count && core < 0; i++)
+        {
+            if (first[i] <= sinc && sinc <= last[i]) core = i;
+            else if (first[i] != last[i] || plan->stages[first[i]].kind != drb_stage_up2x) lone_ups = 0;
+        }
+
+        char const * const wish = getenv("DRB_AMD_FAST_FOLD");   /* diagnostic: 0 keeps them apart */
+
+        if (core > 0 && core <= 3 && lone_ups && !(wish && atoi(wish) == 0))
+        {
+            int folded_first [max_launches], folded_last [max_launches], folded = 0;
+
+            folded_first[0] = 0; folded_last[0] = last[core]; folded = 1;
+
+            for (int i = core + 1; i < count; i++) { folded_first[folded] = first[i]; folded_last[folded] = last[i]; folded++; }
+
+            int const made = make_launches(config, plan, folded_first, folded_last, folded, launches);
+
+            if (made > 0) return made;
+        }
+    }
+
+    return make_launches(config, plan, first, last, count, launches);
+}
+
+/* The launches of a partition of the plan's stages: stages first[i] .. last[i] each. */
+static int make_launches (DrbAmd_Batch_Config const * config, Drb_Plan const * plan, int const * first, int const * last, int count, Fast_Launch * launches)
+{
     for (int i = 0; i < count; i++)
     {
         Fast_Launch * const launch = &launches[i];
@@ -347,19 +384,29 @@ static int build_launches (DrbAmd_Batch_Config const * config, Drb_Plan const * 
         launch->fast.target_layout = i == count - 1 ? (int)config->layout : (int)drb_amd_layout_planar;
         launch->fast.history = geometry.history_frames;
 
-        if (!launch->fast.usable || !drb_hip_fast_kernel_exists(&launch->fast)) return 0;
+        /* the staged kernels exist for some filter lengths only, and for no folded chain */
+        int const folded = launch->fast.pre_ups > 0;
+        int const staged_ok = !folded && drb_hip_fast_kernel_exists(&launch->fast);
+
+        if (!launch->fast.usable) return 0;
 
         /* [up] sinc [down] as one filter on the half-precision matrix instruction
          * where that form applies and its kernel fits (DRB_AMD_FAST_SPLIT=0, a
          * diagnostic, keeps the three stages everywhere) */
         char const * const wish = getenv("DRB_AMD_FAST_SPLIT");
 
-        if (launch->has_sinc && !(wish && atoi(wish) == 0))
+        /* (a sinc stage on its own has nothing to fold: its staged kernel where that
+         * one exists; DRB_AMD_FAST_LONE=1, a diagnostic, takes the split kernel anyway) */
+        char const * const lone_wish = getenv("DRB_AMD_FAST_LONE");
+        int const lone = !launch->fast.has_up && !launch->fast.has_down;
+        int const skip_lone = lone && staged_ok && !(lone_wish && atoi(lone_wish) == 1);
+
+        if (launch->has_sinc && !skip_lone && !(wish && atoi(wish) == 0))
         {
             Drb_Fast_Chain split = launch->fast;
 
             launch->staged = launch->fast;
-            launch->has_staged = 1;
+            launch->has_staged = staged_ok;
 
             if (drb_plan_collapse_geometry(&split, split_lds_budget, 1)
                 && drb_plan_split_geometry(&split, split_lds_budget) && drb_hip_fast_kernel_exists(&split))
@@ -367,6 +414,8 @@ static int build_launches (DrbAmd_Batch_Config const * config, Drb_Plan const * 
                 launch->fast = split;
             }
         }
+
+        if (launch->fast.kind != 4 && !staged_ok) return 0;
     }
 
     return count;

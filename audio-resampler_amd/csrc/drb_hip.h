@@ -70,6 +70,8 @@ typedef struct Drb_Fast_Chain
     int channels, sample_type, layout, history;   /* sample_type, layout: of the source */
     int target_sample_type, target_layout;
     int has_up, up_taps, up_table;          /* half-band in front of the sinc stage   */
+    int pre_ups, pre_taps [3], pre_table [3]; /* collapsed chains: further half-band up-samplers in front of that one,
+                                               the nearest first (a chain of interpolators folded into the one filter) */
     int has_down, down_taps, down_table;    /* half-band behind it                    */
     int sinc_taps, sinc_cubic, sinc_table, sinc_pull;
     int delay_place;                        /* 0 none, 1 behind the sinc stage, 2 in front of it */

@@ -1931,6 +1931,8 @@ Fast_Kernel * pick_kernel (Drb_Fast_Chain const * chain)
         return nullptr;
     }
 
+    if (chain->pre_ups > 0) return nullptr;   // a folded chain of interpolators: the split kernel or none
+
     int const up = chain->has_up ? (chain->up_taps + 16) / 4 : 0;
     int const down = chain->has_down ? (chain->down_taps + 16) / 4 : 0;
     int const key = up * 10000 + chain->ksteps * 100 + down;
@@ -1992,7 +1994,9 @@ extern "C" int drb_hip_launch_collapse_build
     if (job_count <= 0) return 0;
     if (chain->kind != 4 || chain->blocks < 1 || chain->blocks > drb_split_max_blocks) return hipErrorInvalidValue;
 
-    size_t const dynamic = static_cast<size_t>(kBuildOutputs) * (kBuildWide + 32) * sizeof(double);
+    size_t const dynamic = collapse_build_lds_bytes(chain);
+
+    if (dynamic > kBuildLdsLimit) return hipErrorInvalidValue;
 
     hipError_t const status = hipFuncSetAttribute
     (

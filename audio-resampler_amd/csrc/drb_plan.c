@@ -651,12 +651,17 @@ int drb_plan_fast_geometry (Drb_Plan const * plan, int lds_budget_bytes, Drb_Fas
 
     /* shape: at most one 2x stage on either side of a fractional stage */
     int up = -1, down = -1, sinc = -1, delay = -1;
+    int pre [3], pre_count = 0;   /* up-samplers in front of the one next to the sinc stage, in plan order */
 
     for (int k = 0; k < plan->stage_count; k++)
     {
         switch (plan->stages[k].kind)
         {
-          case drb_stage_up2x: if (up >= 0 || sinc >= 0) return 0; up = k; break;
+          case drb_stage_up2x:
+            if (sinc >= 0) return 0;
+            if (up >= 0) { if (pre_count == 3) return 0; pre[pre_count++] = up; }
+            up = k;
+            break;
           case drb_stage_down2x: if (down >= 0) return 0; down = k; break;
           case drb_stage_sinc: sinc = k; break;
           case drb_stage_delay: delay = k; break;
@@ -664,6 +669,8 @@ int drb_plan_fast_geometry (Drb_Plan const * plan, int lds_budget_bytes, Drb_Fas
     }
 
     if (sinc >= 0 && down >= 0 && down < sinc) return 0;
+    if (sinc < 0 && pre_count > 0) return 0;
+    if (pre_count > 0 && delay >= 0 && delay < up) return 0;   /* (a slicer between the interpolators: not folded) */
 
     if (sinc < 0 && up >= 0)
     {
@@ -745,6 +752,18 @@ int drb_plan_fast_geometry (Drb_Plan const * plan, int lds_budget_bytes, Drb_Fas
     chain->has_up = up >= 0;
     chain->up_taps = up >= 0 ? plan->stages[up].arg / 2 : 0;
     chain->up_table = up >= 0 ? half_band_table(plan->stages[up].arg) : 0;
+    /* Further interpolators in front: only the collapsed form takes them in (the
+     * geometry below is that of [up] sinc [down], its basis). */
+    chain->pre_ups = pre_count;
+
+    for (int i = 0; i < pre_count; i++)
+    {
+        Drb_Stage const * const outer = &plan->stages[pre[pre_count - 1 - i]];
+
+        chain->pre_taps[i] = outer->arg / 2;
+        chain->pre_table[i] = half_band_table(outer->arg);
+    }
+
     chain->has_down = down >= 0;
     chain->down_taps = down >= 0 ? plan->stages[down].arg / 2 : 0;
     chain->down_table = down >= 0 ? half_band_table(plan->stages[down].arg) : 0;
@@ -950,15 +969,23 @@ static void collapse_extents (Drb_Fast_Chain const * chain, long long rest, int 
         long long const e_first = parity + collapse_window_end(chain, rest, nu_lo) - chain->sinc_taps;
         long long const e_last = parity + collapse_window_end(chain, rest, nu_hi) - 1;
 
-        lo[b] = (int)(chain->has_up ? floor_div(e_first, 2) - chain->up_taps + 1 : e_first);
-        hi[b] = (int)(chain->has_up ? floor_div(e_last - 1, 2) : e_last) + 1;
+        long long first = chain->has_up ? floor_div(e_first, 2) - chain->up_taps + 1 : e_first;
+        long long last = chain->has_up ? floor_div(e_last - 1, 2) : e_last;
+
+        for (int i = 0; i < chain->pre_ups; i++)
+        {
+            first = floor_div(first, 2) - chain->pre_taps[i] + 1;
+            last = floor_div(last - 1, 2);
+        }
+
+        lo[b] = (int)first;
+        hi[b] = (int)last + 1;
     }
 }
 
 int drb_plan_collapse_geometry (Drb_Fast_Chain * chain, int lds_budget_bytes, int drifting_columns)
 {
     if (!chain->usable || chain->kind != 0) return 0;
-    if (!chain->has_up && !chain->has_down) return 0;   /* one stage: nothing to collapse */
     if (chain->column_drift != 0.0f && !drifting_columns) return 0;
 
     Drb_Fast_Chain c = *chain;
@@ -968,13 +995,18 @@ int drb_plan_collapse_geometry (Drb_Fast_Chain * chain, int lds_budget_bytes, in
     int const ratio_in = (int)(c.period_in / g), ratio_out = (int)(c.period_out / g);
     int m = 0;
 
+    int const ups = (c.has_up ? 1 : 0) + c.pre_ups;
+
     for (int k = 1; k <= 4096 && !m; k++)
     {
         int const seg_s = ratio_out * k, seg_u = ratio_in * k;
         int const seg_y = c.has_down ? seg_s / 2 : seg_s;
 
-        if ((c.has_down && (seg_s & 1)) || (c.has_up && (seg_u & 1))) continue;
+        if ((c.has_down && (seg_s & 1)) || (seg_u & ((1 << ups) - 1))) continue;
         if (seg_y > 192) break;
+        /* (a folded chain of interpolators has short source segments: only odd ones,
+         * whose plane is a straight copy of the source) */
+        if (c.pre_ups > 0 && !((seg_u >> ups) & 1)) continue;
         if (seg_y >= 128) m = k;
     }
 
@@ -987,7 +1019,7 @@ int drb_plan_collapse_geometry (Drb_Fast_Chain * chain, int lds_budget_bytes, in
     c.seg_s = ratio_out * m;
     c.seg_u = ratio_in * m;
     c.seg_y = c.has_down ? c.seg_s / 2 : c.seg_s;
-    c.seg_x = c.has_up ? c.seg_u / 2 : c.seg_u;
+    c.seg_x = c.seg_u >> ups;
     c.blocks = (c.seg_y + 15) / 16;
 
     if (c.blocks > drb_collapse_max_blocks) return 0;
@@ -998,8 +1030,15 @@ int drb_plan_collapse_geometry (Drb_Fast_Chain * chain, int lds_budget_bytes, in
     long long const nu_all = c.has_down ? 2 * (c.seg_y - 1) - 1 - (1 - 2 * c.down_taps) : c.seg_y - 1;
     long long const span_block = floor_div(nu_block * c.target_delta, c.source_delta) + 1 + c.sinc_taps - 1;
     long long const span_all = floor_div(nu_all * c.target_delta, c.source_delta) + 1 + c.sinc_taps - 1;
-    int const width = c.has_up ? (int)(span_block >> 1) + c.up_taps : (int)span_block + 1;
-    int const rows = c.has_up ? (int)(span_all >> 1) + c.up_taps : (int)span_all + 1;
+    int width = c.has_up ? (int)(span_block >> 1) + c.up_taps : (int)span_block + 1;
+    int rows = c.has_up ? (int)(span_all >> 1) + c.up_taps : (int)span_all + 1;
+
+    /* (L frames behind an up-sampler of N taps come from at most L / 2 + N in front of it) */
+    for (int i = 0; i < c.pre_ups; i++)
+    {
+        width = (width >> 1) + c.pre_taps[i];
+        rows = (rows >> 1) + c.pre_taps[i];
+    }
 
     c.ksteps = (width + 3) / 4 | 1;   /* kernel images exist for odd counts */
     c.window = width;
@@ -1059,11 +1098,13 @@ int drb_plan_split_geometry (Drb_Fast_Chain * chain, int lds_budget_bytes)
 
     c.plane_rows = (c.seg_x + c.look_x + 8 + 3) / 4 * 4;
 
-    if (c.plane_rows > 2 * c.seg_x) return 0;   /* a source frame lies in two segments' rows at most */
 
     int const reach = 15 * c.seg_x + c.plane_rows + 31;
 
     c.plane_stride = reach <= 10 * 256 ? 10 * 256 : reach <= 12 * 256 ? 12 * 256 : 0;
+
+    /* (short source segments of a folded chain of interpolators: fewer loads a tile) */
+    if (c.pre_ups > 0) c.plane_stride = reach <= 4 * 256 ? 4 * 256 : reach <= 6 * 256 ? 6 * 256 : c.plane_stride;
 
     if (!c.plane_stride) return 0;
 
@@ -1078,6 +1119,8 @@ int drb_plan_split_geometry (Drb_Fast_Chain * chain, int lds_budget_bytes)
     }
     else
     {
+        if (c.plane_rows > 2 * c.seg_x) return 0;   /* the loaders write a source frame to two segments' rows at most */
+
         c.apart_stride = (c.plane_rows + 4) | 1;
         c.plane_words = 16 * c.apart_stride;
     }
@@ -1112,8 +1155,11 @@ void drb_plan_collapse_key
     long long const mu = q - delay_front;
 
     *rest = at - q * chain->source_delta;
-    *parity = chain->has_up ? (int)(mu & 1) : 0;
-    *frame = chain->has_up ? floor_div(mu, 2) : mu;
+    /* (behind n up-samplers: where in a group of 2^n sinc-input frames the window ends) */
+    int const ups = (chain->has_up ? 1 : 0) + chain->pre_ups;
+
+    *parity = (int)(mu & ((1LL << ups) - 1));
+    *frame = floor_div(mu, 1LL << ups);
 }
 
 int drb_plan_collapse_job (Drb_Fast_Chain const * chain, long long rest, int parity, Drb_Collapse_Job * job)

@@ -167,3 +167,43 @@ def test_fast_mode_whole_ten_second_stream_per_step():
         assert got.shape == want.shape
         assert_close(got, want, "stream %d" % s)
     runner.close()
+
+
+FOLDED = [
+    # (source rate, target rate, channels, quality, 1 where the interpolators fold into one launch, frames)
+    (16000, 48000, 1, support.GOOD, 1, 3 * 16000),
+    (8000, 48000, 2, support.GOOD, 1, 2 * 8000),
+    (16000, 96000, 2, support.GOOD, 1, 2 * 16000),
+    (22050, 96000, 2, support.FINE, 0, 2 * 22050),    # 147 : 160 behind three interpolators: no segment of whole periods fits
+]
+
+
+@pytest.mark.parametrize("src,dst,ch,quality,folds,frames", FOLDED)
+@pytest.mark.parametrize("fold", ["", "0"])
+def test_fast_mode_chains_of_interpolators(src, dst, ch, quality, folds, frames, fold, monkeypatch):
+    """Interpolators in front of the fractional stage's launch folded into its
+    filter (one launch, no intermediate rates in memory), and, as a
+    diagnostic, kept apart: both against the oracle over several tiles and
+    calls."""
+    if fold:
+        monkeypatch.setenv("DRB_AMD_FAST_FOLD", fold)
+    status, plan = support.oracle_plan(src, dst, ch, 256, 16, PUSH, quality)
+    if status != 1:
+        pytest.skip("not a conversion upstream accepts")
+    config = drbamd.make_config(src, dst, ch, 256, 16, PUSH, quality, arithmetic=drbamd.FAST, streams=2)
+    info = drbamd.plan_info(config)
+    if not info.fast_path:
+        pytest.skip("no matrix-core kernel for this chain")
+    if not fold and folds:
+        assert info.fast_launches == 1 and info.fast_collapsed == 2
+    x = support.white_noise(ch, frames, 33)
+    want = support.oracle_push(plan, x)
+    runner = gpu_support.StreamRunner(config, [x, x])
+    schedules = [gpu_support.chunk_schedule(frames, p) for p in ([frames], [frames // 3, 4096, 777])]
+    for i in range(max(len(s) for s in schedules)):
+        runner.step([s[i] if i < len(s) else 0 for s in schedules])
+    for s in range(2):
+        got = runner.result(s)
+        assert got.shape == want.shape
+        assert_close(got, want, "%d -> %d stream %d" % (src, dst, s))
+    runner.close()
