@@ -1495,11 +1495,11 @@ DrbAmd_Status drb_amd_batch_process_host_dense
     size_t const source_stream_bytes = (size_t)source_stream_stride * batch->sample_bytes;
     size_t const target_stream_bytes = (size_t)target_stream_stride * batch->sample_bytes;
 
-    /* slices of about 128 MB (smaller ones leave the link half idle: 16 MB
-     * slices reached 25 GB/s where 128 MB ones reach 55), at least four of
+    /* slices of about 256 MB (smaller ones leave the link partly idle: 64 MB
+     * slices reach 54 GB/s where 256 MB ones reach 74), at least four of
      * them so that the copies of one overlap the conversion of another */
     char const * const tuned = getenv("DRB_AMD_HOST_SLICE_MB");   /* diagnostic */
-    long long const slice_bytes = (long long)(tuned && atoi(tuned) > 0 ? atoi(tuned) : 128) << 20;
+    long long const slice_bytes = (long long)(tuned && atoi(tuned) > 0 ? atoi(tuned) : 256) << 20;
     long long per_slice = slice_bytes / (long long)(source_stream_bytes + target_stream_bytes);
 
     if (per_slice > (n + 3) / 4) per_slice = (n + 3) / 4;
@@ -1510,7 +1510,11 @@ DrbAmd_Status drb_amd_batch_process_host_dense
     if (!code) code = feed_prepare(batch, (size_t)per_slice * source_stream_bytes, (size_t)per_slice * target_stream_bytes);
     if (code) return fail_hip("host feed set-up", code);
 
-    void * const in = batch->feed_streams[0], * const work = batch->feed_streams[1], * const out = batch->feed_streams[2];
+    /* Two streams: copies in on one, conversion and copies out on the other.  (With the
+     * copies out on a stream of their own they ran at 10 GB/s instead of 45 once the
+     * caller's buffers were a few GB: 3.0 instead of 6.7 Gsamples/s for 1024 streams
+     * of 10 s.) */
+    void * const in = batch->feed_streams[0], * const work = batch->feed_streams[1], * const out = work;
     int * const produced = produced_each ? produced_each : batch->dense_produced;
     DrbAmd_Status status = drb_amd_ok;
     int slice = 0;
