@@ -959,7 +959,7 @@ static DrbAmd_Status collapse_prepare
         Drb_Collapse_Spot * const row = spots + (size_t)s * max_stretches;
         int const tiles = (call->target_frames + fast->tile_frames - 1) / fast->tile_frames;
         int const stretches = (tiles + wanted - 1) / wanted;
-        int const every = stretches > 0 ? (tiles + stretches - 1) / stretches : 1;
+        int const every = wanted;   /* a fixed length: streams of one phase share sets whatever their lengths */
 
         /* streams that run in step: the same stretches */
         if (s > 0 && call->phase == call[-1].phase && call->delay == call[-1].delay
