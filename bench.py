@@ -358,6 +358,9 @@ def measure(name, arithmetic, streams, seconds, steps, warmup, rank, world, loca
     mean_step = sum(step_ms) / len(step_ms)
     mean_samples = sum(samples) / len(samples)
     result["roofline"] = roofline_of(info, fast, mean_samples, mean_kernel, mean_step)
+    if fast and info.fast_collapsed and mean_samples / (streams * ch) <= 2 * info.fast_tile_frames:
+        # steps of a tile or two per stream run the staged kernels (drb_batch.c)
+        result["roofline"]["kernel"] = "drb_fast_kernel (steps of at most two tiles per stream)"
     result["dtype"] = ("f32 products from pairs of f16 halves" if fast and info.fast_issued_half_flops_per_output_sample > 0
                        else "f32")
     result["config"] = {
