@@ -1030,8 +1030,8 @@ static DrbAmd_Status collapse_prepare
     if (code == code_no_room) return fail(drb_amd_error_capacity, "the step's coefficient tables do not fit the static workspace");
     if (code) return fail(drb_amd_error_out_of_memory, "coefficient sets: %s", drb_hip_error_text(code));
 
-    code = drb_hip_upload_async(batch->collapse_spots, spots, spots_bytes, hip_stream);
-    if (!code && job_count > 0) code = drb_hip_upload_async(batch->collapse_jobs, jobs, (size_t)job_count * sizeof(Drb_Collapse_Job), hip_stream);
+    code = drb_hip_upload_table(batch->collapse_spots, spots, spots_bytes, hip_stream);
+    if (!code && job_count > 0) code = drb_hip_upload_table(batch->collapse_jobs, jobs, (size_t)job_count * sizeof(Drb_Collapse_Job), hip_stream);
 
     if (code) return fail_hip("coefficient jobs upload", code);
 
@@ -1229,7 +1229,7 @@ DrbAmd_Status drb_amd_batch_process
     }
 
     if (!code && batch->timing) code = drb_hip_event_record(batch->step_start, hip_stream);
-    if (!code) code = drb_hip_upload_async(batch->calls_device, calls, (size_t)n * launches * sizeof(Drb_Device_Call), hip_stream);
+    if (!code) code = drb_hip_upload_table(batch->calls_device, calls, (size_t)n * launches * sizeof(Drb_Device_Call), hip_stream);
 
     /* coefficient sets of the step: they depend on the streams' phases only, not
      * on their samples (built in front of the timed region, which is the filter

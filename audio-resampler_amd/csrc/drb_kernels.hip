@@ -740,6 +740,32 @@ int drb_hip_upload_async (void * device, void const * host, size_t bytes, void *
     return hipMemcpyAsync(device, host, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream));
 }
 
+// A step's tables (descriptors, stretch table, coefficient jobs: some tens of KB in
+// pinned host memory) brought over by a kernel that reads the host memory
+// itself: a DMA copy of that size costs 20-30 us of latency each, this launch 5.
+__global__ __launch_bounds__(256) void drb_table_kernel (unsigned const * __restrict__ host, unsigned * __restrict__ device, unsigned words)
+{
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < words; i += gridDim.x * 256u) device[i] = host[i];
+}
+
+int drb_hip_upload_table (void * device, void const * pinned_host, size_t bytes, void * stream)
+{
+    if (bytes == 0) return 0;
+
+    // (whole 32-bit words of pinned memory; anything else goes the usual way)
+    if ((bytes & 3) || bytes > (64u << 20)) return hipMemcpyAsync(device, pinned_host, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream));
+
+    unsigned const words = static_cast<unsigned>(bytes / 4);
+    unsigned const blocks = (words + 255u) / 256u < 64u ? (words + 255u) / 256u : 64u;
+
+    drb_table_kernel<<<dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream)>>>
+    (
+        static_cast<unsigned const *>(pinned_host), static_cast<unsigned *>(device), words
+    );
+
+    return hipGetLastError();
+}
+
 int drb_hip_download_async (void * host, void const * device, size_t bytes, void * stream)
 {
     return hipMemcpyAsync(host, device, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream));
