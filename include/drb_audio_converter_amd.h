@@ -365,12 +365,14 @@ typedef struct DrbAmd_Plan_Info
                                banded products and the warm-up segment included;
                                one blended kernel per output instead of upstream's
                                two or four dot products)                          */
-    int fast_collapsed;     /* 1: [up2x] sinc [down2x] run as ONE time-varying filter
-                               from source to target frames (its coefficients are
-                               the product of the three stages', so it spends fewer
-                               multiply-adds per sample than upstream's cascade);
-                               2: that filter on the half-precision matrix
-                               instruction, every float32 carried as two halves   */
+    int fast_collapsed;     /* 2: [up2x ...] sinc [down2x] run as ONE time-varying
+                               filter from source to target frames (its coefficients
+                               are the product of the stages', interpolators in
+                               front of the fractional stage's launch folded in
+                               where their ratio allows), on the half-precision
+                               matrix instruction, every float32 carried as two
+                               halves; 0: the stages one after the other (1, the
+                               same filter in float32, is no longer produced)     */
     double fast_issued_half_flops_per_output_sample;  /* the part of
                                fast_issued_flops_per_output_sample that runs on the
                                half-precision instruction (16 times the float32
