@@ -94,3 +94,42 @@ def test_library_exports_every_declared_symbol():
         assert getattr(drbamd.lib, name) is not None
     harness = ctypes.CDLL(drbamd.HARNESS_PATH)
     assert harness.harness_push and harness.harness_pull and harness.harness_sizes
+
+
+def test_which_kernels_a_configuration_gets():
+    """What drb_amd_plan_info reports about the matrix-core path: the benchmark
+    configurations, chains of interpolators folded into one launch, the cases
+    that run the exact kernels (host logic only: no device is touched)."""
+    def info(src, dst, ch, direction, quality, **kw):
+        return drbamd.plan_info(drbamd.make_config(src, dst, ch, 256, 16, direction, quality, **kw))
+
+    fast = dict(arithmetic=drbamd.FAST, streams=4)
+
+    headline = info(44100, 48000, 2, support.PUSH, support.GOOD, **fast)
+    assert (headline.fast_path, headline.fast_launches, headline.fast_collapsed) == (1, 1, 2)
+    assert headline.kernel_name == b"drb_split_kernel" and headline.fast_tile_frames == 16 * 160
+    assert headline.fast_issued_half_flops_per_output_sample == headline.fast_issued_flops_per_output_sample > 0
+
+    # one stage: nothing to fold, the staged kernel
+    poor = info(44100, 48000, 2, support.PUSH, support.POOR, **fast)
+    assert (poor.fast_path, poor.fast_collapsed) == (1, 0) and poor.kernel_name == b"drb_fast_kernel"
+
+    # a lone half-band decimator
+    cfg3 = info(96000, 48000, 8, support.PUSH, support.GOOD, **fast)
+    assert cfg3.fast_path == 1 and cfg3.kernel_name == b"drb_decimate_kernel"
+
+    # interpolators in front of the fractional stage fold into its launch (4 : 3 behind them) ...
+    for src, dst in ((16000, 48000), (8000, 48000), (16000, 96000)):
+        folded = info(src, dst, 1, support.PULL, support.GOOD, **fast)
+        assert (folded.fast_path, folded.fast_launches, folded.fast_collapsed) == (1, 1, 2), (src, dst)
+    # ... and stay launches of their own where no segment of whole periods fits (147 : 160 behind three of them)
+    apart = info(22050, 96000, 2, support.PUSH, support.FINE, **fast)
+    assert apart.fast_path == 1 and apart.fast_launches == 3
+
+    # int32 buffers and exact arithmetic: the exact kernels, whatever was asked for
+    assert info(192000, 44100, 2, support.PUSH, support.BEST, sample_type=drbamd.I32, **fast).fast_path == 0
+    exact = info(44100, 48000, 2, support.PUSH, support.GOOD, streams=4)
+    assert exact.fast_path == 0 and exact.kernel_name == b"drb_cascade_kernel"
+
+    # a ratio whose period is longer than a segment may be: exact
+    assert info(8000, 11025, 2, support.PUSH, support.GOOD, **fast).fast_path == 0
