@@ -997,7 +997,12 @@ int drb_plan_collapse_geometry (Drb_Fast_Chain * chain, int lds_budget_bytes, in
 
     int const ups = (c.has_up ? 1 : 0) + c.pre_ups;
 
-    for (int k = 1; k <= 4096 && !m; k++)
+    /* Among the candidates the one whose last row block is fullest (a row block
+     * costs a wave whether 16 or 1 of its target frames exist), at most ten
+     * blocks where that is possible (the split kernel's limit). */
+    double best = 0.0;
+
+    for (int k = 1; k <= 4096; k++)
     {
         int const seg_s = ratio_out * k, seg_u = ratio_in * k;
         int const seg_y = c.has_down ? seg_s / 2 : seg_s;
@@ -1007,7 +1012,12 @@ int drb_plan_collapse_geometry (Drb_Fast_Chain * chain, int lds_budget_bytes, in
         /* (a folded chain of interpolators has short source segments: only odd ones,
          * whose plane is a straight copy of the source) */
         if (c.pre_ups > 0 && !((seg_u >> ups) & 1)) continue;
-        if (seg_y >= 128) m = k;
+        if (seg_y < 128) continue;
+
+        int const blocks = (seg_y + 15) / 16;
+        double const fill = (double)seg_y / (16.0 * blocks) * (blocks <= drb_split_max_blocks ? 1.0 : 0.01);
+
+        if (fill > best + 1e-9) { best = fill; m = k; }
     }
 
     if (!m) return 0;
