@@ -89,6 +89,7 @@ struct DrbAmd_Batch
     /* collapsed launch (the one with the sinc stage, if its geometry allows):
      * coefficient sets for the distinct phases of a step, and which one every
      * stretch of every stream uses */
+    void * pending_device [3]; void const * pending_host [3]; size_t pending_bytes [3];   /* tables of the step at hand still to be uploaded */
     Drb_Collapse_Job * collapse_jobs;          /* device                       */
     Drb_Collapse_Spot * collapse_spots;        /* device                       */
     unsigned int * collapse_sets;              /* device                       */
@@ -1030,10 +1031,9 @@ static DrbAmd_Status collapse_prepare
     if (code == code_no_room) return fail(drb_amd_error_capacity, "the step's coefficient tables do not fit the static workspace");
     if (code) return fail(drb_amd_error_out_of_memory, "coefficient sets: %s", drb_hip_error_text(code));
 
-    code = drb_hip_upload_table(batch->collapse_spots, spots, spots_bytes, hip_stream);
-    if (!code && job_count > 0) code = drb_hip_upload_table(batch->collapse_jobs, jobs, (size_t)job_count * sizeof(Drb_Collapse_Job), hip_stream);
-
-    if (code) return fail_hip("coefficient jobs upload", code);
+    /* (they travel with the step's descriptors, in one launch: drb_amd_batch_process) */
+    batch->pending_device[0] = batch->collapse_spots; batch->pending_host[0] = spots; batch->pending_bytes[0] = spots_bytes;
+    batch->pending_device[1] = batch->collapse_jobs; batch->pending_host[1] = jobs; batch->pending_bytes[1] = (size_t)job_count * sizeof(Drb_Collapse_Job);
 
     *max_stretches_out = max_stretches;
     *job_count_out = job_count;
@@ -1179,6 +1179,8 @@ DrbAmd_Status drb_amd_batch_process
     int const tile = batch->geometry.tile_frames;
 
     int collapse_stretches = 1, collapse_job_count = 0;
+
+    batch->pending_bytes[0] = batch->pending_bytes[1] = 0;   /* (set by collapse_prepare where a step needs them) */
     int apart [max_launches];   /* 1: this step runs the launch's three stages apart */
 
     HOST_MARK(1);
@@ -1229,7 +1231,13 @@ DrbAmd_Status drb_amd_batch_process
     }
 
     if (!code && batch->timing) code = drb_hip_event_record(batch->step_start, hip_stream);
-    if (!code) code = drb_hip_upload_table(batch->calls_device, calls, (size_t)n * launches * sizeof(Drb_Device_Call), hip_stream);
+    if (!code)
+    {
+        batch->pending_device[2] = batch->calls_device; batch->pending_host[2] = calls;
+        batch->pending_bytes[2] = (size_t)n * launches * sizeof(Drb_Device_Call);
+
+        code = drb_hip_upload_tables(batch->pending_device, batch->pending_host, batch->pending_bytes, 3, hip_stream);
+    }
 
     /* coefficient sets of the step: they depend on the streams' phases only, not
      * on their samples (built in front of the timed region, which is the filter

@@ -165,8 +165,8 @@ int drb_hip_host_alloc (void ** pointer, size_t bytes);
 int drb_hip_host_free (void * pointer);
 int drb_hip_memset_async (void * pointer, int value, size_t bytes, void * stream);
 int drb_hip_upload_async (void * device, void const * host, size_t bytes, void * stream);
-/* the same for a small table in pinned host memory (hipHostMalloc), fetched by a kernel instead of a DMA engine */
-int drb_hip_upload_table (void * device, void const * pinned_host, size_t bytes, void * stream);
+/* the same for up to three small tables in pinned host memory (hipHostMalloc), fetched by one kernel instead of DMA engines */
+int drb_hip_upload_tables (void * const * device, void const * const * pinned_host, size_t const * bytes, int count, void * stream);
 int drb_hip_download_async (void * host, void const * device, size_t bytes, void * stream);
 int drb_hip_stream_synchronize (void * stream);
 int drb_hip_stream_create (void ** stream);

@@ -741,27 +741,61 @@ int drb_hip_upload_async (void * device, void const * host, size_t bytes, void *
 }
 
 // A step's tables (descriptors, stretch table, coefficient jobs: some tens of KB in
-// pinned host memory) brought over by a kernel that reads the host memory
+// pinned host memory) brought over by ONE kernel that reads the host memory
 // itself: a DMA copy of that size costs 20-30 us of latency each, this launch 5.
-__global__ __launch_bounds__(256) void drb_table_kernel (unsigned const * __restrict__ host, unsigned * __restrict__ device, unsigned words)
+struct Drb_Table_Copies
 {
-    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < words; i += gridDim.x * 256u) device[i] = host[i];
+    unsigned const * host [3];
+    unsigned * device [3];
+    unsigned words [3];
+};
+
+__global__ __launch_bounds__(256) void drb_table_kernel (Drb_Table_Copies const copies)
+{
+    #pragma unroll
+    for (int t = 0; t < 3; t++)
+    {
+        unsigned const * const host = copies.host[t];
+        unsigned * const device = copies.device[t];
+
+        for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < copies.words[t]; i += gridDim.x * 256u) device[i] = host[i];
+    }
 }
 
-int drb_hip_upload_table (void * device, void const * pinned_host, size_t bytes, void * stream)
+int drb_hip_upload_tables (void * const * device, void const * const * pinned_host, size_t const * bytes, int count, void * stream)
 {
-    if (bytes == 0) return 0;
+    Drb_Table_Copies copies = {};
+    unsigned most = 0;
+    int used = 0;
 
-    // (whole 32-bit words of pinned memory; anything else goes the usual way)
-    if ((bytes & 3) || bytes > (64u << 20)) return hipMemcpyAsync(device, pinned_host, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream));
+    for (int t = 0; t < count; t++)
+    {
+        if (bytes[t] == 0) continue;
 
-    unsigned const words = static_cast<unsigned>(bytes / 4);
-    unsigned const blocks = (words + 255u) / 256u < 64u ? (words + 255u) / 256u : 64u;
+        // (whole 32-bit words of pinned memory, three tables a launch; anything else goes the usual way)
+        if ((bytes[t] & 3) || bytes[t] > (64u << 20) || used == 3)
+        {
+            hipError_t const status = hipMemcpyAsync(device[t], pinned_host[t], bytes[t], hipMemcpyHostToDevice, static_cast<hipStream_t>(stream));
 
-    drb_table_kernel<<<dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream)>>>
-    (
-        static_cast<unsigned const *>(pinned_host), static_cast<unsigned *>(device), words
-    );
+            if (status != hipSuccess) return status;
+
+            continue;
+        }
+
+        copies.host[used] = static_cast<unsigned const *>(pinned_host[t]);
+        copies.device[used] = static_cast<unsigned *>(device[t]);
+        copies.words[used] = static_cast<unsigned>(bytes[t] / 4);
+
+        if (copies.words[used] > most) most = copies.words[used];
+
+        used++;
+    }
+
+    if (!used) return 0;
+
+    unsigned const blocks = (most + 255u) / 256u < 64u ? (most + 255u) / 256u : 64u;
+
+    drb_table_kernel<<<dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(copies);
 
     return hipGetLastError();
 }
