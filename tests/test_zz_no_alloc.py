@@ -22,6 +22,7 @@ CASES = [
     ("exact", drbamd.EXACT, 44100, 48000, 2, support.GOOD, 5),
     ("fast, split matrix-core kernel", drbamd.FAST, 44100, 48000, 2, support.GOOD, 6),
     ("fast, one decimator", drbamd.FAST, 96000, 48000, 8, support.GOOD, 3),
+    ("fast, interpolators folded into the split kernel", drbamd.FAST, 16000, 48000, 1, support.GOOD, 5),
 ]
 
 
