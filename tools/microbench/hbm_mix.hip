@@ -62,6 +62,34 @@ __global__ __launch_bounds__(1024) void copy_tiles (float const * __restrict__ i
     }
 }
 
+// the tile pattern with the loads of BATCH tiles in front of their stores
+template <int BATCH>
+__global__ __launch_bounds__(1024) void copy_tiles_batched (float const * __restrict__ in, float * __restrict__ out, int rows, int tiles, int stride, long long in_row, long long out_row)
+{
+    int const row = blockIdx.x % rows;
+    float const * const from = in + row * in_row;
+    float * const to = out + row * out_row;
+    int const lane = threadIdx.x;
+
+    for (int tile = blockIdx.x / rows; tile < tiles; tile += stride * BATCH)
+    {
+        float4_t v [BATCH];
+
+        #pragma unroll
+        for (int b = 0; b < BATCH; b++)
+        {
+            v[b] = float4_t{ 0, 0, 0, 0 };
+            if (lane < 588 && tile + b * stride < tiles) v[b] = *reinterpret_cast<float4_t const *>(from + 2352LL * (tile + b * stride) + 4 * lane);
+        }
+
+        #pragma unroll
+        for (int b = 0; b < BATCH; b++)
+        {
+            if (lane < 640 && tile + b * stride < tiles) *reinterpret_cast<float4_t *>(to + 2560LL * (tile + b * stride) + 4 * lane) = v[b];
+        }
+    }
+}
+
 // the same with twice as much read as written: tiles of 5120 floats in, 2560 out
 __global__ __launch_bounds__(1024) void copy_tiles_2to1 (float const * __restrict__ in, float * __restrict__ out, int rows, int tiles, int stride, long long in_row, long long out_row)
 {
@@ -150,6 +178,17 @@ int main ()
             timed(name, 4.0 * rows * tiles * (2352.0 + 2560.0),
                   [&] { copy_tiles<<<grid, 1024>>>(in, out, rows, tiles, stride, in_row, out_row); });
         }
+    }
+
+    {
+        int const rows = 2048, tiles = 187;
+        long long const in_row = 441088, out_row = 480000;
+        double const bytes = 4.0 * rows * tiles * (2352.0 + 2560.0);
+
+        timed("tiles, 2048 workgroups, loads of 2 tiles batched", bytes, [&] { copy_tiles_batched<2><<<rows, 1024>>>(in, out, rows, tiles, 1, in_row, out_row); });
+        timed("tiles, 2048 workgroups, loads of 4 tiles batched", bytes, [&] { copy_tiles_batched<4><<<rows, 1024>>>(in, out, rows, tiles, 1, in_row, out_row); });
+        timed("tiles, 2048 workgroups, loads of 8 tiles batched", bytes, [&] { copy_tiles_batched<8><<<rows, 1024>>>(in, out, rows, tiles, 1, in_row, out_row); });
+        timed("tiles, 2048 workgroups, loads of 16 tiles batched", bytes, [&] { copy_tiles_batched<16><<<rows, 1024>>>(in, out, rows, tiles, 1, in_row, out_row); });
     }
 
     // a half-band decimator's pattern: 4096 x 8 rows of 960 000 frames in and 480 000 out
