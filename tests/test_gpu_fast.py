@@ -207,3 +207,55 @@ def test_fast_mode_chains_of_interpolators(src, dst, ch, quality, folds, frames,
         assert got.shape == want.shape
         assert_close(got, want, "%d -> %d stream %d" % (src, dst, s))
     runner.close()
+
+
+RAGGED = [
+    # (source rate, target rate, channels, direction, streams, frames per stream at most (user side))
+    (44100, 48000, 2, PUSH, 23, 60000),
+    (16000, 48000, 1, PULL, 29, 90000),     # two interpolators folded into the fractional stage's filter
+    (48000, 44100, 2, PUSH, 11, 50000),
+]
+
+
+@pytest.mark.parametrize("src,dst,ch,direction,n,most", RAGGED)
+def test_fast_mode_ragged_streams_with_a_reset(src, dst, ch, direction, n, most):
+    """Every stream its own length and its own step pattern (steps of no frames,
+    of a few hundred, of tens of thousands: the step's longest stream picks the
+    kernel, so the staged and the split kernels hand a stream's history to
+    each other), and one stream started over in the middle: each stream against
+    an upstream converter of its own."""
+    rng = np.random.default_rng(src + n)
+    status, plan = support.oracle_plan(src, dst, ch, 256, 16, direction, support.GOOD)
+    assert status == 1
+    config = drbamd.make_config(src, dst, ch, 256, 16, direction, support.GOOD, arithmetic=drbamd.FAST, streams=n)
+    assert drbamd.plan_info(config).fast_path == 1
+    inputs = [support.white_noise(ch, most, 300 + s) for s in range(n)]
+    totals = [int(v) for v in rng.integers(most // 4, most, n)]
+    totals[0] = 0
+    runner = gpu_support.StreamRunner(config, inputs)
+    left = list(totals)
+    again, restarted, step_index = 3, False, 0
+    while any(left):
+        limit = (300, 5000, 40000)[step_index % 3]
+        steps = [min(l, int(rng.integers(0, limit))) for l in left]
+        runner.step(steps)
+        left = [l - s for l, s in zip(left, steps)]
+        step_index += 1
+        if step_index == 4 and not restarted:
+            # stream `again` starts over: what it made so far is dropped
+            runner.batch.reset(again, 1)
+            runner.read[again] = 0
+            runner.outputs[again] = []
+            left[again] = totals[again]
+            restarted = True
+    assert restarted
+    for s in range(n):
+        if direction == PUSH:
+            want = support.oracle_push(plan, inputs[s][:, :totals[s]])
+        else:
+            want, _ = support.oracle_pull(plan, inputs[s], totals[s])
+        got = runner.result(s)
+        assert got.shape == want.shape, s
+        if want.size:
+            assert_close(got, want, "stream %d" % s)
+    runner.close()
