@@ -215,6 +215,8 @@ static void build_chain (DrbAmd_Batch_Config const * config, Drb_Plan const * pl
     }
 }
 
+enum { lds_budget = 56 * 1024, fast_lds_budget = 78 * 1024, split_lds_budget = 160 * 1024 };
+
 static DrbAmd_Status resolve (DrbAmd_Batch_Config const * config, Drb_Plan * plan)
 {
     int const status = drb_plan_resolve
@@ -231,6 +233,16 @@ static DrbAmd_Status resolve (DrbAmd_Batch_Config const * config, Drb_Plan * pla
                     plan->throttling == 0 ? "max_block_count leaves no room for a single sub-block"
                                           : "a 2x stage would see odd frame counts (block_size 1 without a slicer)");
     }
+    {
+        Drb_Geometry geometry;
+
+        drb_plan_geometry(plan, lds_budget, &geometry);
+
+        if (geometry.lds_bytes > drb_lds_hard_limit)
+        {
+            return fail(drb_amd_error_unsupported, "the chain's look-back times %d channels does not fit a workgroup's LDS", plan->channels);
+        }
+    }
     if ((unsigned)config->sample_type > drb_amd_sample_i32) return fail(drb_amd_error_bad_argument, "unknown sample type");
     if ((unsigned)config->layout > drb_amd_layout_interleaved) return fail(drb_amd_error_bad_argument, "unknown layout");
     if ((unsigned)config->arithmetic > drb_amd_arithmetic_fast) return fail(drb_amd_error_bad_argument, "unknown arithmetic mode");
@@ -238,7 +250,6 @@ static DrbAmd_Status resolve (DrbAmd_Batch_Config const * config, Drb_Plan * pla
     return drb_amd_ok;
 }
 
-enum { lds_budget = 56 * 1024, fast_lds_budget = 78 * 1024, split_lds_budget = 160 * 1024 };
 
 /* ---- plan -> launches of the matrix-core path -------------------------------- */
 

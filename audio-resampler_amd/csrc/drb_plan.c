@@ -364,6 +364,12 @@ int drb_plan_resolve
         Drb_Pass const pass = plan->passes[i];
         Drb_Edge const * const in = pull ? &plan->edges[i + 1] : &plan->edges[i];
         Drb_Edge const * const out = pull ? &plan->edges[i] : &plan->edges[i + 1];
+        /* (de)interleaving is fused into the first load / last store: no stage, and
+         * with eight stages in front of it no room for one either */
+        if (pass.kind != drb_pass_up2x && pass.kind != drb_pass_down2x && pass.kind != drb_pass_sinc && pass.kind != drb_pass_slicer) continue;
+
+        if (plan->stage_count >= drb_max_stages) return -1;
+
         Drb_Stage * const stage = &plan->stages[plan->stage_count];
 
         stage->in_rate = in->rate;
@@ -399,7 +405,7 @@ int drb_plan_resolve
             plan->slicer_block = stage->arg;
             break;
           default:
-            continue; /* (de)interleaving is fused into the first load / last store */
+            break;
         }
 
         plan->stage_count++;
@@ -559,27 +565,37 @@ void drb_plan_geometry (Drb_Plan const * plan, int lds_budget_bytes, Drb_Geometr
     geometry->history_frames = (int)((-lo + 4 + 3) / 4 * 4);
     if (geometry->history_frames < 4) geometry->history_frames = 4;
 
-    static int const tiles [] = { 2048, 1024, 512, 256, 128, 64, 32, 16 };
+    static int const tiles [] = { 2048, 1024, 512, 256, 128, 64, 32, 16, 8, 4 };
 
-    for (unsigned t = 0; t < sizeof(tiles) / sizeof(tiles[0]); t++)
+    /* The largest tile within the budget (which leaves room for a second workgroup
+     * on the CU); chains that decimate many channels a long way have none, and
+     * get the largest one that fits a workgroup's LDS at all. */
+    for (int pass = 0; pass < 2; pass++)
     {
-        long long width = tiles[t], widest = tiles[t];
+        int const limit = pass == 0 ? lds_budget_bytes : drb_lds_hard_limit;
 
-        for (int k = plan->stage_count - 1; k >= 0; k--)
+        for (unsigned t = 0; t < sizeof(tiles) / sizeof(tiles[0]); t++)
         {
-            width = input_width(plan, &plan->stages[k], width);
-            if (width > widest) widest = width;
+            if (pass == 0 && tiles[t] < 16) break;   /* (tiles that small are mostly look-back) */
+
+            long long width = tiles[t], widest = tiles[t];
+
+            for (int k = plan->stage_count - 1; k >= 0; k--)
+            {
+                width = input_width(plan, &plan->stages[k], width);
+                if (width > widest) widest = width;
+            }
+
+            /* stages read whole 4-float groups, up to 15 floats past their range;
+             * two-plane edges split the width in halves of whole groups */
+            widest = (widest + 16 + 7) / 8 * 8;
+
+            geometry->tile_frames = tiles[t];
+            geometry->lds_width = (int)widest;
+            geometry->lds_bytes = (int)(2 * widest * plan->channels * 4);
+
+            if (geometry->lds_bytes <= limit) return;
         }
-
-        /* stages read whole 4-float groups, up to 15 floats past their range;
-         * two-plane edges split the width in halves of whole groups */
-        widest = (widest + 16 + 7) / 8 * 8;
-
-        geometry->tile_frames = tiles[t];
-        geometry->lds_width = (int)widest;
-        geometry->lds_bytes = (int)(2 * widest * plan->channels * 4);
-
-        if (geometry->lds_bytes <= lds_budget_bytes) break;
     }
 }
 

@@ -126,6 +126,11 @@ typedef struct Drb_Geometry
 }
 Drb_Geometry;
 
+/* what a workgroup of the cascade kernel may take of the CU's 160 KB for its two
+ * staging buffers (the coefficient bank and the index ranges come on top) */
+enum { drb_lds_hard_limit = 148 * 1024 };
+
+/* geometry->lds_bytes is above drb_lds_hard_limit where no tile fits: such a plan does not run */
 void drb_plan_geometry (Drb_Plan const * plan, int lds_budget_bytes, Drb_Geometry * geometry);
 
 struct Drb_Fast_Chain;

@@ -522,12 +522,17 @@ static void sinc_stage
     }
 }
 
-/* y[j] = x[j - B/2]: drb-audio-converter.c:2502-2652, 2684-2688 */
-static void slicer_stage (int block, float const * x, long in_frames, long frames, float * y)
+/* Push: y[j] = x[j - B/2] (drb-audio-converter.c:2502-2575, 2684-2688).  Pull: the
+ * block starts at index B/2 and hands out its B - B/2 remaining frames of
+ * silence before it fetches anything (drb-audio-converter.c:2592-2606), so
+ * y[j] = x[j - (B - B/2)]: the same for every even B, one frame later for B = 1. */
+static void slicer_stage (int pull, int block, float const * x, long in_frames, long frames, float * y)
 {
+    int const delay = pull ? block - block / 2 : block / 2;
+
     for (long j = 0; j < frames; j++)
     {
-        y[j] = at(x, in_frames, j - block / 2);
+        y[j] = at(x, in_frames, j - delay);
     }
 }
 
@@ -562,7 +567,7 @@ static int run_channel
             down2x(plan->stage_arg[i], current, n_in, n_out, next);
             break;
           case drb_oracle_stage_slicer:
-            slicer_stage(plan->stage_arg[i], current, n_in, n_out, next);
+            slicer_stage(plan->direction, plan->stage_arg[i], current, n_in, n_out, next);
             break;
           case drb_oracle_stage_sinc:
             sinc_stage

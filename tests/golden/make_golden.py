@@ -58,6 +58,11 @@ STREAM_CASES = [
     ("r48k_to_8k_pull", 48000, 8000, 1, 4, 64, PULL, GOOD, 12000),
     ("r11025_to_60k_pull_fine", 11025, 60000, 5, 16, 16, PULL, FINE, 1500),
     ("r240k_to_22050_push_poor", 240000, 22050, 2, 64, 8, PUSH, POOR, 20000),
+    # a slicer of block 1 in the pull direction (its first frame is the silence it starts with)
+    ("cfg1_pull_poor_bs1", 44100, 48000, 2, 1, 64, PULL, POOR, 3000),
+    # the longest chains there are: five 2x stages on one side of the fractional stage, one on the other
+    ("r8k_to_96k_push_fine", 8000, 96000, 2, 64, 64, PUSH, FINE, 1200),
+    ("r192k_to_16k_push_fine", 192000, 16000, 2, 256, 4, PUSH, FINE, 30000),
 ]
 
 SIGNALS = ["noise", "sweep"]

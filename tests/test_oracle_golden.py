@@ -182,3 +182,33 @@ def test_oracle_against_upstream_build_live():
         assert np.array_equal(bits(got), bits(want)), (src, dst, ch, bs, mbc, direction, quality)
         assert support.oracle_callback_counts(plan, chunks).tolist() == counts.tolist()
         done += 1
+
+
+@pytest.mark.skipif(not support.have_ref(), reason="upstream build only exists in the build container")
+@pytest.mark.parametrize("case", [
+    (8000, 11025, 2, 1, 64, PULL, support.POOR),     # a slicer of block 1 in the pull direction: one frame of silence first
+    (44100, 48000, 2, 1, 2, PULL, support.POOR),
+    (44100, 48000, 2, 1, 16, PULL, support.GOOD),
+    (8000, 96000, 2, 64, 64, PUSH, support.FINE),    # eight stages: five interpolators, fractional stage, slicer, decimator
+    (192000, 16000, 2, 256, 4, PUSH, support.FINE),  # eight stages the other way
+    (8000, 96000, 2, 1, 1, PULL, support.GOOD),
+])
+def test_oracle_against_upstream_build_corner_chains(case):
+    src, dst, ch, bs, mbc, direction, quality = case
+    ref = support.ref_harness()
+    status, plan = support.oracle_plan(src, dst, ch, bs, mbc, direction, quality)
+    assert status == 1 and plan.consistent
+    chunks = [300, 40, 0, 7000]
+    if direction == PUSH:
+        x = support.white_noise(ch, sum(chunks), 11)
+        want, counts = ref.push(src, dst, ch, bs, mbc, quality, x, chunks)
+        got = support.oracle_push(plan, x)
+    else:
+        need = support.oracle_lib().drb_oracle_pull_count(plan, sum(chunks))
+        x = support.white_noise(ch, max(int(need), 1), 11)
+        want, counts, consumed = ref.pull(src, dst, ch, bs, mbc, quality, x, chunks)
+        got, used = support.oracle_pull(plan, x, sum(chunks))
+        assert used == consumed
+    assert got.shape == want.shape
+    assert np.array_equal(bits(got), bits(want))
+    assert support.oracle_callback_counts(plan, chunks).tolist() == counts.tolist()

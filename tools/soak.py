@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""Randomised parity run on the GPU: conversions drawn from everything the
+upstream planner accepts (13 x 13 rates, 4 qualities, 2 directions, 1-8
+channels, 7 block sizes), with random sample type, layout, arithmetic, stream
+count and step pattern, each stream against the oracle (the CPU restatement of
+upstream under oracle/): exact arithmetic bit for bit, fast arithmetic within
+1e-6 + 1e-5 |want| (float32) or one step (int16).
+
+usage: python3 tools/soak.py [--seconds 120] [--seed 1] [--arithmetic exact|fast|both]
+Prints one line per failing case and a summary; exit status 1 on any failure."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "audio-resampler_amd"))
+
+import support  # noqa: E402
+import drbamd  # noqa: E402
+import gpu_support  # noqa: E402
+
+
+def draw(rng, arithmetic):
+    while True:
+        src, dst = (int(v) for v in rng.choice(support.RATES, 2))
+        ch = int(rng.integers(1, 9))
+        bs = int(rng.choice(support.BLOCK_SIZES))
+        mbc = int(rng.choice([1, 2, 16, 64]))
+        direction = int(rng.integers(0, 2))
+        quality = int(rng.integers(0, 4))
+        status, plan = support.oracle_plan(src, dst, ch, bs, mbc, direction, quality)
+        if status != 1:
+            continue
+        sample = int(rng.choice([drbamd.F32, drbamd.F32, drbamd.I16, drbamd.I32]))
+        layout = int(rng.choice([drbamd.PLANAR, drbamd.INTERLEAVED]))
+        which = arithmetic if arithmetic != "both" else str(rng.choice(["exact", "fast"]))
+        return dict(src=src, dst=dst, ch=ch, bs=bs, mbc=mbc, direction=direction, quality=quality,
+                    sample=sample, layout=layout, arithmetic=which, streams=int(rng.integers(1, 6))), plan
+
+
+def run_case(case, plan, rng, even):
+    arithmetic = drbamd.FAST if case["arithmetic"] == "fast" else drbamd.EXACT
+    try:
+        config = drbamd.make_config(case["src"], case["dst"], case["ch"], case["bs"], case["mbc"], case["direction"],
+                                    case["quality"], sample_type=case["sample"], layout=case["layout"],
+                                    arithmetic=arithmetic, streams=case["streams"])
+        info = drbamd.plan_info(config)
+    except drbamd.DrbError:
+        return "unsupported"
+    n, ch = case["streams"], case["ch"]
+    pull = case["direction"] == support.PULL
+    # user-side frames per stream: a few tiles' worth at the faster of the two rates
+    most = int(rng.integers(2000, 60000))
+    ratio = case["src"] / case["dst"]
+    source_most = int(most * ratio) + 4096 if pull else most
+    noise = [support.white_noise(ch, source_most + 8192, int(rng.integers(1, 1 << 30))) for _ in range(n)]
+    if case["sample"] == drbamd.I16:
+        inputs = [np.round(x * 32767).astype(np.int16) for x in noise]
+    elif case["sample"] == drbamd.I32:
+        inputs = [np.round(x.astype(np.float64) * (2 ** 24 - 1)).astype(np.int32) * 128 for x in noise]
+    else:
+        inputs = noise
+    totals = [int(v) for v in rng.integers(0, most + 1, n)]
+    # (a step whose frame count reaches a 2x decimator odd is refused: such chains get multiples of 16)
+    totals = [t // even * even for t in totals]
+    runner = gpu_support.StreamRunner(config, inputs)
+    left = list(totals)
+    try:
+        while any(left):
+            limit = int(rng.choice([64, 700, 5000, 70000]))
+            steps = [min(l, int(rng.integers(0, limit)) // even * even) for l in left]
+            if not any(steps):
+                steps = [min(l, even * 8) for l in left]
+            runner.step(steps)
+            left = [l - s for l, s in zip(left, steps)]
+        for s in range(n):
+            xf = inputs[s] if case["sample"] == drbamd.F32 else support.oracle_convert_samples(inputs[s], "f32").reshape(inputs[s].shape)
+            if pull:
+                want_f, _ = support.oracle_pull(plan, xf, totals[s])
+            else:
+                want_f = support.oracle_push(plan, xf[:, :totals[s]])
+            got = runner.result(s) if totals[s] or runner.outputs[s] else np.zeros((ch, 0))
+            if case["sample"] == drbamd.F32:
+                want = want_f
+            else:
+                to = "i16" if case["sample"] == drbamd.I16 else "i32"
+                want = support.oracle_convert_samples(np.ascontiguousarray(want_f), to).reshape(want_f.shape)
+            if got.shape != want.shape:
+                return "shape %s against %s (stream %d)" % (got.shape, want.shape, s)
+            if not want.size:
+                continue
+            exact = case["arithmetic"] == "exact" or not info.fast_path
+            if case["sample"] == drbamd.F32:
+                if exact:
+                    if not np.array_equal(got.view(np.uint32), want.view(np.uint32)):
+                        return "stream %d differs (exact)" % s
+                else:
+                    excess = np.abs(got.astype(np.float64) - want) - (1e-6 + 1e-5 * np.abs(want))
+                    if excess.max() > 0:
+                        return "stream %d: |err| %.3g beyond the bound by %.3g" % (s, np.abs(got - want).max(), excess.max())
+            else:
+                diff = np.abs(got.astype(np.int64) - want.astype(np.int64)).max()
+                if diff > (0 if exact else 1):
+                    return "stream %d: %d steps off" % (s, diff)
+    finally:
+        runner.close()
+    return "fast" if (case["arithmetic"] == "fast" and info.fast_path) else "exact"
+
+
+def main():
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--seconds", type=float, default=120.0)
+    parser.add_argument("--seed", type=int, default=1)
+    parser.add_argument("--arithmetic", default="both", choices=["exact", "fast", "both"])
+    args = parser.parse_args()
+    rng = np.random.default_rng(args.seed)
+    started = time.time()
+    tally, failures, last_print = {}, 0, started
+    while time.time() - started < args.seconds:
+        case, plan = draw(rng, args.arithmetic)
+        try:
+            state = rng.bit_generator.state
+            try:
+                outcome = run_case(case, plan, rng, 1)
+            except drbamd.DrbError as error:
+                if "odd frame count" not in str(error):
+                    raise
+                rng.bit_generator.state = state
+                outcome = run_case(case, plan, rng, 16)
+        except Exception as error:  # a step the library refused, or a helper's assertion
+            outcome = "error: %s" % (str(error)[:200] or type(error).__name__)
+        if outcome in ("fast", "exact", "unsupported"):
+            tally[outcome] = tally.get(outcome, 0) + 1
+        else:
+            failures += 1
+            print("FAIL", case, outcome, flush=True)
+        if time.time() - last_print > 30:
+            last_print = time.time()
+            print("... %d s: %s, %d failures" % (last_print - started, tally, failures), flush=True)
+    print("cases: %s; failures: %d" % (tally, failures))
+    return 1 if failures else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
