@@ -53,8 +53,9 @@ def run_case(case, plan, rng, even):
         return "unsupported"
     n, ch = case["streams"], case["ch"]
     pull = case["direction"] == support.PULL
-    # user-side frames per stream: a few tiles' worth at the faster of the two rates
-    most = int(rng.integers(2000, 60000))
+    # user-side frames per stream: a few tiles' worth, now and then a few hundred (the
+    # split kernel's coefficient sets change every 64 tiles)
+    most = int(rng.integers(2000, 60000)) if rng.integers(0, 8) else int(rng.integers(200000, 500000))
     ratio = case["src"] / case["dst"]
     source_most = int(most * ratio) + 4096 if pull else most
     noise = [support.white_noise(ch, source_most + 8192, int(rng.integers(1, 1 << 30))) for _ in range(n)]
@@ -71,7 +72,7 @@ def run_case(case, plan, rng, even):
     left = list(totals)
     try:
         while any(left):
-            limit = int(rng.choice([64, 700, 5000, 70000]))
+            limit = int(rng.choice([64, 700, 5000, 70000])) if most < 100000 else int(rng.choice([5000, 70000, 600000]))
             steps = [min(l, int(rng.integers(0, limit)) // even * even) for l in left]
             if not any(steps):
                 steps = [min(l, even * 8) for l in left]
@@ -111,6 +112,19 @@ def run_case(case, plan, rng, even):
     return "fast" if (case["arithmetic"] == "fast" and info.fast_path) else "exact"
 
 
+def run_one(case, plan, rng):
+    """run_case, over again with frame counts in multiples of 16 where a step was
+    refused because an odd count reached a 2x decimator"""
+    state = rng.bit_generator.state
+    try:
+        return run_case(case, plan, rng, 1)
+    except drbamd.DrbError as error:
+        if "odd frame count" not in str(error):
+            raise
+    rng.bit_generator.state = state
+    return run_case(case, plan, rng, 16)
+
+
 def main():
     parser = argparse.ArgumentParser()
     parser.add_argument("--seconds", type=float, default=120.0)
@@ -123,14 +137,7 @@ def main():
     while time.time() - started < args.seconds:
         case, plan = draw(rng, args.arithmetic)
         try:
-            state = rng.bit_generator.state
-            try:
-                outcome = run_case(case, plan, rng, 1)
-            except drbamd.DrbError as error:
-                if "odd frame count" not in str(error):
-                    raise
-                rng.bit_generator.state = state
-                outcome = run_case(case, plan, rng, 16)
+            outcome = run_one(case, plan, rng)
         except Exception as error:  # a step the library refused, or a helper's assertion
             outcome = "error: %s" % (str(error)[:200] or type(error).__name__)
         if outcome in ("fast", "exact", "unsupported"):
