@@ -190,6 +190,7 @@ static void build_chain (DrbAmd_Batch_Config const * config, Drb_Plan const * pl
     chain->history = geometry->history_frames;
     chain->tile_frames = geometry->tile_frames;
     chain->lds_width = geometry->lds_width;
+    chain->channel_group = geometry->channel_group > 0 ? geometry->channel_group : plan->channels;
     chain->sample_type = config->sample_type;
     chain->layout = config->layout;
     chain->source_delta = plan->source_delta > 0 ? plan->source_delta : 1;

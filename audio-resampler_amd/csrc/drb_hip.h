@@ -33,7 +33,7 @@ typedef struct Drb_Device_Chain
     int lds_width;           /* floats per channel per staging buffer            */
     int sample_type;         /* DrbAmd_Sample_Type                               */
     int layout;              /* DrbAmd_Layout                                    */
-    int reserved;
+    int channel_group;       /* channels a workgroup takes through the chain     */
     long long source_delta;  /* 2^48 / fractional stage input rate               */
     long long target_delta;  /* 2^48 / fractional stage output rate              */
     double scale;            /* 1.0 / source_delta                               */

@@ -448,11 +448,13 @@ __global__ __launch_bounds__(kThreads) void drb_cascade_kernel
     int const last = min(first + chain.tile_frames, call.target_frames);
     int const stages = chain.stage_count;
     int const width = chain.lds_width;
-    int const channels = chain.channels;
+    // this workgroup's channels: channel_0 .. channel_0 + channels - 1 of the stream's
+    int const channel_0 = blockIdx.y * chain.channel_group;
+    int const channels = min(chain.channel_group, chain.channels - channel_0);
 
     // (offsets from the one LDS array, not an array of pointers: the compiler then
     // keeps every access an LDS instruction instead of a flat one)
-    int const buffer_floats = channels * width;
+    int const buffer_floats = chain.channel_group * width;
     float * const bank = lds + 2 * buffer_floats;
     Ranges & ranges = *reinterpret_cast<Ranges *>(bank + bank_floats);
 
@@ -536,7 +538,7 @@ __global__ __launch_bounds__(kThreads) void drb_cascade_kernel
         int const lo = ranges.lo[0], count = ranges.hi[0] - ranges.lo[0];
         int const shift = chain.delay_edge == 0 ? call.delay : 0;
         int const split = stages > 0 && chain.stages[0].kind == kStageDown2x;
-        float const * const stream_history = history + static_cast<long long>(stream) * channels * chain.history;
+        float const * const stream_history = history + static_cast<long long>(stream) * chain.channels * chain.history;
 
         if (chain.layout == kInterleaved)
         {
@@ -544,7 +546,7 @@ __global__ __launch_bounds__(kThreads) void drb_cascade_kernel
             {
                 int const position = i / channels, channel = i - position * channels;
                 float const v = source_frame(chain, call, stream_history, source_channel_stride,
-                                             channel, lo + position - shift);
+                                             channel_0 + channel, lo + position - shift);
                 put(lds + channel * width, width, split, position, v);
             }
         }
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(kThreads) void drb_cascade_kernel
                 for (int position = threadIdx.x; position < count; position += kThreads)
                 {
                     float const v = source_frame(chain, call, stream_history, source_channel_stride,
-                                                 channel, lo + position - shift);
+                                                 channel_0 + channel, lo + position - shift);
                     put(lds + channel * width, width, split, position, v);
                 }
             }
@@ -619,7 +621,7 @@ __global__ __launch_bounds__(kThreads) void drb_cascade_kernel
             for (int i = threadIdx.x; i < count * channels; i += kThreads)
             {
                 int const position = i / channels, channel = i - position * channels;
-                store_sample(target, static_cast<long long>(first + position) * channels + channel,
+                store_sample(target, static_cast<long long>(first + position) * chain.channels + channel_0 + channel,
                              chain.sample_type, result[channel * width + position]);
             }
         }
@@ -629,7 +631,7 @@ __global__ __launch_bounds__(kThreads) void drb_cascade_kernel
             {
                 for (int position = threadIdx.x; position < count; position += kThreads)
                 {
-                    store_sample(target, channel * target_channel_stride + first + position,
+                    store_sample(target, (channel_0 + channel) * target_channel_stride + first + position,
                                  chain.sample_type, result[channel * width + position]);
                 }
             }
@@ -890,7 +892,11 @@ int drb_hip_launch_cascade
 
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
 
-    drb_cascade_kernel<<<dim3(static_cast<unsigned>(blocks)), dim3(kThreads), dynamic, static_cast<hipStream_t>(stream)>>>
+    if (chain->channel_group < 1 || chain->channel_group > chain->channels) return hipErrorInvalidValue;
+
+    unsigned const groups = static_cast<unsigned>((chain->channels + chain->channel_group - 1) / chain->channel_group);
+
+    drb_cascade_kernel<<<dim3(static_cast<unsigned>(blocks), groups), dim3(kThreads), dynamic, static_cast<hipStream_t>(stream)>>>
     (
         *chain, calls, stream_count, history,
         source_channel_stride, target_channel_stride, bank_floats, fault_flag

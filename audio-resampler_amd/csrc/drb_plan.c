@@ -568,33 +568,43 @@ void drb_plan_geometry (Drb_Plan const * plan, int lds_budget_bytes, Drb_Geometr
     static int const tiles [] = { 2048, 1024, 512, 256, 128, 64, 32, 16, 8, 4 };
 
     /* The largest tile within the budget (which leaves room for a second workgroup
-     * on the CU); chains that decimate many channels a long way have none, and
-     * get the largest one that fits a workgroup's LDS at all. */
+     * on the CU), all channels in one workgroup.  Chains that decimate many
+     * channels a long way have none: their channels are dealt out to several
+     * workgroups (half of them each, a quarter, one), and failing that a
+     * workgroup takes its whole LDS. */
     for (int pass = 0; pass < 2; pass++)
     {
         int const limit = pass == 0 ? lds_budget_bytes : drb_lds_hard_limit;
 
-        for (unsigned t = 0; t < sizeof(tiles) / sizeof(tiles[0]); t++)
+        for (int share = 1; share <= 8; share *= 2)
         {
-            if (pass == 0 && tiles[t] < 16) break;   /* (tiles that small are mostly look-back) */
+            int const group = (plan->channels + share - 1) / share;
 
-            long long width = tiles[t], widest = tiles[t];
-
-            for (int k = plan->stage_count - 1; k >= 0; k--)
+            for (unsigned t = 0; t < sizeof(tiles) / sizeof(tiles[0]); t++)
             {
-                width = input_width(plan, &plan->stages[k], width);
-                if (width > widest) widest = width;
+                if (pass == 0 && tiles[t] < 16) break;   /* (tiles that small are mostly look-back) */
+
+                long long width = tiles[t], widest = tiles[t];
+
+                for (int k = plan->stage_count - 1; k >= 0; k--)
+                {
+                    width = input_width(plan, &plan->stages[k], width);
+                    if (width > widest) widest = width;
+                }
+
+                /* stages read whole 4-float groups, up to 15 floats past their range;
+                 * two-plane edges split the width in halves of whole groups */
+                widest = (widest + 16 + 7) / 8 * 8;
+
+                geometry->tile_frames = tiles[t];
+                geometry->lds_width = (int)widest;
+                geometry->channel_group = group;
+                geometry->lds_bytes = (int)(2 * widest * group * 4);
+
+                if (geometry->lds_bytes <= limit) return;
             }
 
-            /* stages read whole 4-float groups, up to 15 floats past their range;
-             * two-plane edges split the width in halves of whole groups */
-            widest = (widest + 16 + 7) / 8 * 8;
-
-            geometry->tile_frames = tiles[t];
-            geometry->lds_width = (int)widest;
-            geometry->lds_bytes = (int)(2 * widest * plan->channels * 4);
-
-            if (geometry->lds_bytes <= limit) return;
+            if (group == 1) break;
         }
     }
 }

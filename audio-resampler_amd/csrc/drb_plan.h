@@ -123,6 +123,7 @@ typedef struct Drb_Geometry
     int tile_frames;        /* target frames per workgroup                      */
     int lds_width;          /* floats per channel per staging buffer            */
     int lds_bytes;          /* dynamic LDS per workgroup                        */
+    int channel_group;      /* channels per workgroup                           */
 }
 Drb_Geometry;
 
