@@ -30,3 +30,16 @@ def test_random_conversions_against_the_oracle(seed, arithmetic):
         assert outcome in ("fast", "exact", "unsupported"), (case, outcome)
         tally[outcome] = tally.get(outcome, 0) + 1
     assert tally.get("unsupported", 0) < 10, tally
+
+
+def test_random_conversions_through_the_drop_in():
+    """The four-function API on the GPU: samples bit for bit and the callbacks'
+    frame counts, against the oracle."""
+    rng = np.random.default_rng(21)
+    tally = {}
+    for _ in range(150):
+        case, plan = soak.draw(rng, "exact")
+        outcome = soak.run_api_case(case, plan, rng)
+        assert outcome in ("api", "unsupported"), (case, outcome)
+        tally[outcome] = tally.get(outcome, 0) + 1
+    assert tally.get("api", 0) > 100, tally

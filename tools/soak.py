@@ -6,7 +6,7 @@ count and step pattern, each stream against the oracle (the CPU restatement of
 upstream under oracle/): exact arithmetic bit for bit, fast arithmetic within
 1e-6 + 1e-5 |want| (float32) or one step (int16).
 
-usage: python3 tools/soak.py [--seconds 120] [--seed 1] [--arithmetic exact|fast|both]
+usage: python3 tools/soak.py [--seconds 120] [--seed 1] [--arithmetic exact|fast|both] [--api]
 Prints one line per failing case and a summary; exit status 1 on any failure."""
 import argparse
 import os
@@ -112,6 +112,55 @@ def run_case(case, plan, rng, even):
     return "fast" if (case["arithmetic"] == "fast" and info.fast_path) else "exact"
 
 
+_harness = None
+
+
+def run_api_case(case, plan, rng):
+    """The four-function drop-in on the GPU (through the harness that also drives
+    the upstream build): samples bit for bit and the callbacks' frame counts."""
+    global _harness
+    if _harness is None:
+        _harness = support.ApiHarness(drbamd.HARNESS_PATH)
+    if not plan.consistent:
+        return "unsupported"
+    src, dst, ch, bs, mbc, direction, quality = (case[k] for k in ("src", "dst", "ch", "bs", "mbc", "direction", "quality"))
+    chunks = [int(v) for v in rng.integers(0, int(rng.choice([40, 900, 6000])), int(rng.integers(1, 7)))]
+    if _harness.sizes(src, dst, ch, bs, mbc, direction, quality) == (0, 0):
+        return "unsupported"
+    # Upstream plans a few chains whose sub-block does not fit its own work buffer (e.g.
+    # mono 11025 -> 44100, block size 1: 64 frames in, 256 out, 128 floats of buffer) and
+    # writes past it; the drop-in stops the process there instead.  Nothing to compare.
+    info = drbamd.plan_info(drbamd.make_config(src, dst, ch, bs, mbc, direction, quality))
+    count = support.oracle_lib().drb_oracle_pull_count if direction == support.PULL else support.oracle_lib().drb_oracle_push_count
+    most = max(int(count(plan, info.throttling * k)) - int(count(plan, info.throttling * (k - 1))) for k in range(1, 40))
+    if max(most, info.throttling) * ch > info.buffer_length:
+        return "unsupported"
+    if direction == support.PUSH:
+        x = support.white_noise(ch, max(sum(chunks), 1), int(rng.integers(1, 1 << 30)))
+        result = _harness.push(src, dst, ch, bs, mbc, quality, x, chunks)
+        if result is None:
+            return "unsupported"
+        got, counts = result
+        want = support.oracle_push(plan, x[:, :sum(chunks)])
+    else:
+        need = support.oracle_lib().drb_oracle_pull_count(plan, sum(chunks))
+        x = support.white_noise(ch, max(int(need), 1), int(rng.integers(1, 1 << 30)))
+        result = _harness.pull(src, dst, ch, bs, mbc, quality, x, chunks)
+        if result is None:
+            return "unsupported"
+        got, counts, consumed = result
+        want, used = support.oracle_pull(plan, x, sum(chunks))
+        if used != consumed:
+            return "consumed %d against %d" % (consumed, used)
+    if got.shape != want.shape:
+        return "shape %s against %s" % (got.shape, want.shape)
+    if want.size and not np.array_equal(np.ascontiguousarray(got).view(np.uint32), np.ascontiguousarray(want).view(np.uint32)):
+        return "samples differ"
+    if support.oracle_callback_counts(plan, chunks).tolist() != counts.tolist():
+        return "callback counts differ"
+    return "api"
+
+
 def run_one(case, plan, rng):
     """run_case, over again with frame counts in multiples of 16 where a step was
     refused because an odd count reached a 2x decimator"""
@@ -130,17 +179,20 @@ def main():
     parser.add_argument("--seconds", type=float, default=120.0)
     parser.add_argument("--seed", type=int, default=1)
     parser.add_argument("--arithmetic", default="both", choices=["exact", "fast", "both"])
+    parser.add_argument("--api", action="store_true", help="the four-function drop-in instead of the batched entry point")
     args = parser.parse_args()
     rng = np.random.default_rng(args.seed)
     started = time.time()
     tally, failures, last_print = {}, 0, started
     while time.time() - started < args.seconds:
         case, plan = draw(rng, args.arithmetic)
+        if os.environ.get("DRB_SOAK_TRACE"):
+            print("case", case, flush=True)   # (the drop-in aborts where upstream has no error to return)
         try:
-            outcome = run_one(case, plan, rng)
+            outcome = run_api_case(case, plan, rng) if args.api else run_one(case, plan, rng)
         except Exception as error:  # a step the library refused, or a helper's assertion
             outcome = "error: %s" % (str(error)[:200] or type(error).__name__)
-        if outcome in ("fast", "exact", "unsupported"):
+        if outcome in ("fast", "exact", "api", "unsupported"):
             tally[outcome] = tally.get(outcome, 0) + 1
         else:
             failures += 1
