@@ -312,10 +312,10 @@ extern DrbAmd_Status drb_amd_batch_process_dense_static
 
 /* The same with source and target in HOST memory (pinned memory copies at the
  * link's speed; pageable memory works, slowly): streams are handed to the
- * device in slices of about 128 MB, and one slice's copies run while another is
- * being converted (three internal HIP streams, three slices in flight, staging
- * buffers owned by the batch and grown on demand).  Blocks until every target
- * is back in host memory.  No counterpart upstream, whose caller's thread does
+ * device in slices of about 256 MB, and one slice's copy in runs while another
+ * is converted and copied back (two internal HIP streams, three slices in
+ * flight, staging buffers owned by the batch and grown on demand).  Blocks
+ * until every target is back in host memory.  No counterpart upstream, whose caller's thread does
  * the filtering; it is what a host-side data loader calls. */
 extern DrbAmd_Status drb_amd_batch_process_host_dense
     (

@@ -6,7 +6,7 @@ count and step pattern, each stream against the oracle (the CPU restatement of
 upstream under oracle/): exact arithmetic bit for bit, fast arithmetic within
 1e-6 + 1e-5 |want| (float32) or one step (int16).
 
-usage: python3 tools/soak.py [--seconds 120] [--seed 1] [--arithmetic exact|fast|both] [--api]
+usage: python3 tools/soak.py [--seconds 120] [--seed 1] [--arithmetic exact|fast|both] [--api | --dense]
 Prints one line per failing case and a summary; exit status 1 on any failure."""
 import argparse
 import os
@@ -112,6 +112,107 @@ def run_case(case, plan, rng, even):
     return "fast" if (case["arithmetic"] == "fast" and info.fast_path) else "exact"
 
 
+def run_dense_case(case, plan, rng):
+    """The dense entry points (uniform batches): device-resident, the one that
+    allocates nothing, and host-fed, drawn at random, several steps each."""
+    import ctypes
+    import torch
+    arithmetic = drbamd.FAST if case["arithmetic"] == "fast" else drbamd.EXACT
+    n, ch = case["streams"], case["ch"]
+    try:
+        config = drbamd.make_config(case["src"], case["dst"], ch, case["bs"], case["mbc"], case["direction"],
+                                    case["quality"], sample_type=case["sample"], layout=case["layout"],
+                                    arithmetic=arithmetic, streams=n)
+        info = drbamd.plan_info(config)
+    except drbamd.DrbError:
+        return "unsupported"
+    pull = case["direction"] == support.PULL
+    entry = str(rng.choice(["dense", "static", "host"]))
+    steps = [int(v) // 16 * 16 for v in rng.integers(0, int(rng.choice([600, 9000, 50000])), int(rng.integers(1, 5)))]
+    total = sum(steps)
+    if total == 0:
+        return "unsupported"
+    count = support.oracle_lib().drb_oracle_pull_count if pull else support.oracle_lib().drb_oracle_push_count
+    other_total = int(count(plan, total))
+    source_total = other_total if pull else total
+    np_type = gpu_support.NP_TYPES[case["sample"]]
+    noise = [support.white_noise(ch, source_total + 64, int(rng.integers(1, 1 << 30))) for _ in range(n)]
+    if case["sample"] == drbamd.I16:
+        inputs = [np.round(x * 32767).astype(np.int16) for x in noise]
+    elif case["sample"] == drbamd.I32:
+        inputs = [np.round(x.astype(np.float64) * (2 ** 24 - 1)).astype(np.int32) * 128 for x in noise]
+    else:
+        inputs = noise
+    interleaved = case["layout"] == drbamd.INTERLEAVED
+    batch = drbamd.Batch(config)
+    got = [[] for _ in range(n)]
+    read = 0
+    try:
+        for frames in steps:
+            other = batch.query([frames] * n)[0]
+            take, make = (other, frames) if pull else (frames, other)
+            capacity = (take if pull else make) + int(rng.integers(0, 40))
+            room = max(make, capacity if not pull else make, 1)
+            chunk = np.stack([x[:, read:read + take] for x in inputs])                     # [n, ch, take]
+            chunk = np.concatenate([chunk, np.zeros((n, ch, max(1, take) - take), np_type)], 2) if take == 0 else chunk
+            width = chunk.shape[2]
+            host_source = np.ascontiguousarray(chunk.transpose(0, 2, 1) if interleaved else chunk)
+            host_target = np.full((n, room, ch) if interleaved else (n, ch, room), 7, np_type)
+            produced = (ctypes.c_int * n)()
+            source_strides = (width * ch, 0 if interleaved else width)
+            target_strides = (room * ch, 0 if interleaved else room)
+            bound = take if pull else room
+            if entry == "host":
+                source = torch.from_numpy(host_source).pin_memory()
+                target = torch.from_numpy(host_target).pin_memory()
+                batch.process_host_dense(source.data_ptr(), *source_strides, target.data_ptr(), *target_strides,
+                                         frames, bound, produced=produced)
+                result = target.numpy()
+            else:
+                source = torch.from_numpy(host_source).cuda()
+                target = torch.from_numpy(host_target).cuda()
+                stream = torch.cuda.current_stream().cuda_stream
+                call = batch.process_dense_static if entry == "static" else batch.process_dense
+                try:
+                    call(source.data_ptr(), *source_strides, target.data_ptr(), *target_strides,
+                         frames, bound, stream=stream, produced=produced)
+                except drbamd.DrbError as error:
+                    if entry == "static" and error.status == "capacity":
+                        return "unsupported"   # (a chain of several launches that has not run a step this long yet)
+                    raise
+                batch.synchronize(stream)
+                result = target.cpu().numpy()
+            if list(produced) != [other] * n:
+                return "%s: produced %s against %d" % (entry, list(produced)[:4], other)
+            for s in range(n):
+                got[s].append(np.ascontiguousarray(result[s, :make, :].T) if interleaved else result[s, :, :make].copy())
+            read += take
+        for s in range(n):
+            xf = inputs[s] if case["sample"] == drbamd.F32 else support.oracle_convert_samples(inputs[s], "f32").reshape(inputs[s].shape)
+            want_f = support.oracle_pull(plan, xf, total)[0] if pull else support.oracle_push(plan, xf[:, :total])
+            want = want_f if case["sample"] == drbamd.F32 else support.oracle_convert_samples(
+                np.ascontiguousarray(want_f), "i16" if case["sample"] == drbamd.I16 else "i32").reshape(want_f.shape)
+            result = np.concatenate(got[s], axis=1)
+            if result.shape != want.shape:
+                return "%s: shape %s against %s (stream %d)" % (entry, result.shape, want.shape, s)
+            if not want.size:
+                continue
+            exact = case["arithmetic"] == "exact" or not info.fast_path
+            if case["sample"] == drbamd.F32:
+                if exact and not np.array_equal(result.view(np.uint32), want.view(np.uint32)):
+                    return "%s: stream %d differs (exact)" % (entry, s)
+                excess = np.abs(result.astype(np.float64) - want) - (1e-6 + 1e-5 * np.abs(want))
+                if excess.max() > 0:
+                    return "%s: stream %d beyond the bound by %.3g" % (entry, s, excess.max())
+            else:
+                diff = np.abs(result.astype(np.int64) - want.astype(np.int64)).max()
+                if diff > (0 if exact else 1):
+                    return "%s: stream %d: %d steps off" % (entry, s, diff)
+    finally:
+        batch.close()
+    return "fast" if (case["arithmetic"] == "fast" and info.fast_path) else "exact"
+
+
 _harness = None
 
 
@@ -180,6 +281,7 @@ def main():
     parser.add_argument("--seed", type=int, default=1)
     parser.add_argument("--arithmetic", default="both", choices=["exact", "fast", "both"])
     parser.add_argument("--api", action="store_true", help="the four-function drop-in instead of the batched entry point")
+    parser.add_argument("--dense", action="store_true", help="the dense entry points (device-resident, static workspace, host-fed)")
     args = parser.parse_args()
     rng = np.random.default_rng(args.seed)
     started = time.time()
@@ -189,7 +291,7 @@ def main():
         if os.environ.get("DRB_SOAK_TRACE"):
             print("case", case, flush=True)   # (the drop-in aborts where upstream has no error to return)
         try:
-            outcome = run_api_case(case, plan, rng) if args.api else run_one(case, plan, rng)
+            outcome = run_api_case(case, plan, rng) if args.api else run_dense_case(case, plan, rng) if args.dense else run_one(case, plan, rng)
         except Exception as error:  # a step the library refused, or a helper's assertion
             outcome = "error: %s" % (str(error)[:200] or type(error).__name__)
         if outcome in ("fast", "exact", "api", "unsupported"):
