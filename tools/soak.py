@@ -24,6 +24,9 @@ import drbamd  # noqa: E402
 import gpu_support  # noqa: E402
 
 
+MOST_STREAMS = 5
+
+
 def draw(rng, arithmetic):
     while True:
         src, dst = (int(v) for v in rng.choice(support.RATES, 2))
@@ -39,7 +42,7 @@ def draw(rng, arithmetic):
         layout = int(rng.choice([drbamd.PLANAR, drbamd.INTERLEAVED]))
         which = arithmetic if arithmetic != "both" else str(rng.choice(["exact", "fast"]))
         return dict(src=src, dst=dst, ch=ch, bs=bs, mbc=mbc, direction=direction, quality=quality,
-                    sample=sample, layout=layout, arithmetic=which, streams=int(rng.integers(1, 6))), plan
+                    sample=sample, layout=layout, arithmetic=which, streams=int(rng.integers(1, MOST_STREAMS + 1))), plan
 
 
 def run_case(case, plan, rng, even):
@@ -54,8 +57,10 @@ def run_case(case, plan, rng, even):
     n, ch = case["streams"], case["ch"]
     pull = case["direction"] == support.PULL
     # user-side frames per stream: a few tiles' worth, now and then a few hundred (the
-    # split kernel's coefficient sets change every 64 tiles)
+    # split kernel's coefficient sets change every 64 tiles); batches of many streams: short ones
     most = int(rng.integers(2000, 60000)) if rng.integers(0, 8) else int(rng.integers(200000, 500000))
+    if n > 16:
+        most = int(rng.integers(500, 9000))
     ratio = case["src"] / case["dst"]
     source_most = int(most * ratio) + 4096 if pull else most
     noise = [support.white_noise(ch, source_most + 8192, int(rng.integers(1, 1 << 30))) for _ in range(n)]
@@ -78,7 +83,7 @@ def run_case(case, plan, rng, even):
                 steps = [min(l, even * 8) for l in left]
             runner.step(steps)
             left = [l - s for l, s in zip(left, steps)]
-        for s in range(n):
+        for s in (range(n) if n <= 16 else sorted(int(v) for v in rng.choice(n, 16, replace=False))):
             xf = inputs[s] if case["sample"] == drbamd.F32 else support.oracle_convert_samples(inputs[s], "f32").reshape(inputs[s].shape)
             if pull:
                 want_f, _ = support.oracle_pull(plan, xf, totals[s])
@@ -280,9 +285,12 @@ def main():
     parser.add_argument("--seconds", type=float, default=120.0)
     parser.add_argument("--seed", type=int, default=1)
     parser.add_argument("--arithmetic", default="both", choices=["exact", "fast", "both"])
+    parser.add_argument("--streams", type=int, default=5, help="streams per batch, at most (beyond 16: short streams, 16 of them checked)")
     parser.add_argument("--api", action="store_true", help="the four-function drop-in instead of the batched entry point")
     parser.add_argument("--dense", action="store_true", help="the dense entry points (device-resident, static workspace, host-fed)")
     args = parser.parse_args()
+    global MOST_STREAMS
+    MOST_STREAMS = args.streams
     rng = np.random.default_rng(args.seed)
     started = time.time()
     tally, failures, last_print = {}, 0, started
