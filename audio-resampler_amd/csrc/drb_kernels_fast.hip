@@ -46,7 +46,8 @@ constexpr int kMaxTypes = 3;         // row-block types a wave keeps sinc coeffi
 // of noise, 44.1 -> 48 kHz good, worst |error| against upstream: 4.8e-7 rebuilding
 // every tile or every 8, 7.2e-7 every 16, 9.5e-7 every 32, 1.7e-6 (over the
 // bound) every 64 (tools/drift_probe.py).  20 leaves a stream of 19 tiles (1 s at
-// 48 kHz) with one rebuild, in its middle.
+// 48 kHz) with one rebuild, in its middle.  (44.1 -> 48 kHz moves 1.7e-8 source
+// frames per segment, 176.4 -> 192 kHz 4.5e-8, the most among the 13 rates.)
 constexpr int kRebuild = 20;
 
 enum { kSampleF32 = 0, kSampleI16 = 1, kSampleI32 = 2 };
@@ -1272,7 +1273,10 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_fast_kernel
     // its segment 0, so that only the stream's first tile spends a segment on
     // warming up; otherwise every tile does.
     bool const carry = tile_stride == 1 && !chain.no_carry;
-    int const rebuild_span = rebuild_every * (carry ? 16 : 15 * tile_stride);   // segments between rebuilds
+    // segments from the first to the last of the tiles that one build serves (this
+    // workgroup's tiles lie tile_stride apart: a build per tile serves that tile alone,
+    // however far away the workgroup's next one is)
+    int const rebuild_span = (rebuild_every - 1) * (carry ? 16 : 15 * tile_stride);
 
     auto place = [&] (int index) -> Tile
     {

@@ -41,6 +41,14 @@ def draw(rng, arithmetic):
         sample = int(rng.choice([drbamd.F32, drbamd.F32, drbamd.I16, drbamd.I32]))
         layout = int(rng.choice([drbamd.PLANAR, drbamd.INTERLEAVED]))
         which = arithmetic if arithmetic != "both" else str(rng.choice(["exact", "fast"]))
+        if arithmetic == "fast" and rng.integers(0, 8):
+            # (most draws have no matrix-core kernel and would run the exact ones: draw again, most of the time)
+            try:
+                if not drbamd.plan_info(drbamd.make_config(src, dst, ch, bs, mbc, direction, quality, sample_type=sample,
+                                                           layout=layout, arithmetic=drbamd.FAST)).fast_path:
+                    continue
+            except drbamd.DrbError:
+                continue
         return dict(src=src, dst=dst, ch=ch, bs=bs, mbc=mbc, direction=direction, quality=quality,
                     sample=sample, layout=layout, arithmetic=which, streams=int(rng.integers(1, MOST_STREAMS + 1))), plan
 
