@@ -1250,13 +1250,18 @@ __global__ __launch_bounds__(kMaxThreads, 3) void drb_fast_kernel
     // of this workgroup's tiles, which lie tile_stride apart
     // (a walk over all of a stream's tiles spreads its rebuilds evenly: 19 tiles
     // are one stretch of 19, not 16 + 3)
-    int rebuild_every = max(1, (chain.rebuild_tiles > 0 ? chain.rebuild_tiles : kRebuild) / tile_stride);
+    // kRebuild was measured at 44.1 -> 48 kHz, which drifts 1.74e-8 source frames per
+    // segment; rate pairs that drift faster (176.4 <-> 192 kHz: 4.5e-8 and 4.8e-8) rebuild
+    // that much more often, so that the drift a build is followed over stays the same
+    float const drift_size = fabsf(drift_per_segment);
+    int const cadence = drift_size > 1.8e-8f ? max(2, static_cast<int>(static_cast<float>(kRebuild) * 1.8e-8f / drift_size)) : kRebuild;
+    int rebuild_every = max(1, (chain.rebuild_tiles > 0 ? chain.rebuild_tiles : cadence) / tile_stride);
 
     if (tile_stride == 1 && !chain.no_carry && chain.rebuild_tiles <= 0)
     {
         int const segments = (call.target_frames + chain.seg_y - 1) / chain.seg_y;
         int const tiles = segments > 15 ? 1 + (segments - 15 + 15) / 16 : 1;
-        int const stretches = (tiles + kRebuild - 1) / kRebuild;
+        int const stretches = (tiles + cadence - 1) / cadence;
 
         rebuild_every = (tiles + stretches - 1) / stretches;
     }
