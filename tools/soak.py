@@ -6,7 +6,7 @@ count and step pattern, each stream against the oracle (the CPU restatement of
 upstream under oracle/): exact arithmetic bit for bit, fast arithmetic within
 1e-6 + 1e-5 |want| (float32) or one step (int16).
 
-usage: python3 tools/soak.py [--seconds 120] [--seed 1] [--arithmetic exact|fast|both] [--api | --dense]
+usage: python3 tools/soak.py [--seconds 120] [--seed 1] [--arithmetic exact|fast|both] [--api | --dense | --scale]
 Prints one line per failing case and a summary; exit status 1 on any failure."""
 import argparse
 import os
@@ -226,6 +226,82 @@ def run_dense_case(case, plan, rng):
     return "fast" if (case["arithmetic"] == "fast" and info.fast_path) else "exact"
 
 
+def run_scale_case(case, plan, rng):
+    """Batches of hundreds to thousands of streams and steps of many tiles (what the
+    benchmark runs, at configurations drawn at random): samples made on the
+    device, a few streams checked."""
+    import ctypes
+    import torch
+    if case["sample"] == drbamd.I32:
+        return "unsupported"
+    arithmetic = drbamd.FAST if case["arithmetic"] == "fast" else drbamd.EXACT
+    ch = case["ch"]
+    pull = case["direction"] == support.PULL
+    steps = [int(v) // 16 * 16 for v in rng.integers(20000, 160000, int(rng.integers(1, 4)))]
+    total = sum(steps)
+    count = support.oracle_lib().drb_oracle_pull_count if pull else support.oracle_lib().drb_oracle_push_count
+    other_total = int(count(plan, total))
+    source_total, target_total = (other_total, total) if pull else (total, other_total)
+    n = int(rng.integers(300, 2000))
+    n = max(16, min(n, int(6e9 / (4.0 * ch * max(source_total, target_total, 1)))))
+    try:
+        config = drbamd.make_config(case["src"], case["dst"], ch, case["bs"], case["mbc"], case["direction"],
+                                    case["quality"], sample_type=case["sample"], layout=drbamd.PLANAR,
+                                    arithmetic=arithmetic, streams=n)
+        info = drbamd.plan_info(config)
+    except drbamd.DrbError:
+        return "unsupported"
+    generator = torch.Generator(device="cuda:0")
+    generator.manual_seed(int(rng.integers(1, 1 << 30)))
+    if case["sample"] == drbamd.I16:
+        source = torch.randint(-32767, 32768, (n, ch, source_total + 64), device="cuda:0", dtype=torch.int16, generator=generator)
+    else:
+        source = torch.rand((n, ch, source_total + 64), device="cuda:0", generator=generator) * 2.0 - 1.0
+    width = source.shape[2]
+    room = target_total + 4096
+    target = torch.zeros((n, ch, room), device="cuda:0", dtype=source.dtype)
+    size = source.element_size()
+    batch = drbamd.Batch(config)
+    stream = torch.cuda.current_stream().cuda_stream
+    read = made = 0
+    try:
+        for frames in steps:
+            other = batch.query([frames] * n)[0]
+            take, make = (other, frames) if pull else (frames, other)
+            produced = (ctypes.c_int * n)()
+            batch.process_dense(source.data_ptr() + size * read, ch * width, width,
+                                target.data_ptr() + size * made, ch * room, room,
+                                frames, take if pull else room - made, stream=stream, produced=produced)
+            if list(produced) != [other] * n:
+                return "produced %s against %d" % (list(produced)[:4], other)
+            read += take
+            made += make
+        batch.synchronize(stream)
+        exact = case["arithmetic"] == "exact" or not info.fast_path
+        for s in sorted(set([0, n - 1] + [int(v) for v in rng.integers(0, n, 3)])):
+            x = source[s].cpu().numpy()
+            xf = x if case["sample"] == drbamd.F32 else support.oracle_convert_samples(x, "f32").reshape(x.shape)
+            want_f = support.oracle_pull(plan, xf, total)[0] if pull else support.oracle_push(plan, xf[:, :total])
+            want = want_f if case["sample"] == drbamd.F32 else support.oracle_convert_samples(np.ascontiguousarray(want_f), "i16").reshape(want_f.shape)
+            got = target[s, :, :made].cpu().numpy()
+            if got.shape != want.shape:
+                return "shape %s against %s (stream %d of %d)" % (got.shape, want.shape, s, n)
+            if case["sample"] == drbamd.F32:
+                if exact and not np.array_equal(got.view(np.uint32), want.view(np.uint32)):
+                    return "stream %d of %d differs (exact)" % (s, n)
+                excess = np.abs(got.astype(np.float64) - want) - (1e-6 + 1e-5 * np.abs(want))
+                if excess.max() > 0:
+                    return "stream %d of %d: |err| %.3g beyond the bound by %.3g (%s)" % (
+                        s, n, np.abs(got.astype(np.float64) - want).max(), excess.max(), info.kernel_name.decode())
+            else:
+                diff = np.abs(got.astype(np.int64) - want.astype(np.int64)).max()
+                if diff > (0 if exact else 1):
+                    return "stream %d of %d: %d steps off" % (s, n, diff)
+    finally:
+        batch.close()
+    return "fast" if (case["arithmetic"] == "fast" and info.fast_path) else "exact"
+
+
 _harness = None
 
 
@@ -295,6 +371,7 @@ def main():
     parser.add_argument("--arithmetic", default="both", choices=["exact", "fast", "both"])
     parser.add_argument("--streams", type=int, default=5, help="streams per batch, at most (beyond 16: short streams, 16 of them checked)")
     parser.add_argument("--api", action="store_true", help="the four-function drop-in instead of the batched entry point")
+    parser.add_argument("--scale", action="store_true", help="batches of hundreds of streams and steps of many tiles, a few streams checked")
     parser.add_argument("--dense", action="store_true", help="the dense entry points (device-resident, static workspace, host-fed)")
     args = parser.parse_args()
     global MOST_STREAMS
@@ -307,7 +384,8 @@ def main():
         if os.environ.get("DRB_SOAK_TRACE"):
             print("case", case, flush=True)   # (the drop-in aborts where upstream has no error to return)
         try:
-            outcome = run_api_case(case, plan, rng) if args.api else run_dense_case(case, plan, rng) if args.dense else run_one(case, plan, rng)
+            outcome = (run_api_case(case, plan, rng) if args.api else run_dense_case(case, plan, rng) if args.dense
+                       else run_scale_case(case, plan, rng) if args.scale else run_one(case, plan, rng))
         except Exception as error:  # a step the library refused, or a helper's assertion
             outcome = "error: %s" % (str(error)[:200] or type(error).__name__)
         if outcome in ("fast", "exact", "api", "unsupported"):
