@@ -246,20 +246,24 @@ def run_scale_case(case, plan, rng):
     n = max(16, min(n, int(6e9 / (4.0 * ch * max(source_total, target_total, 1)))))
     try:
         config = drbamd.make_config(case["src"], case["dst"], ch, case["bs"], case["mbc"], case["direction"],
-                                    case["quality"], sample_type=case["sample"], layout=drbamd.PLANAR,
+                                    case["quality"], sample_type=case["sample"], layout=case["layout"],
                                     arithmetic=arithmetic, streams=n)
         info = drbamd.plan_info(config)
     except drbamd.DrbError:
         return "unsupported"
     generator = torch.Generator(device="cuda:0")
     generator.manual_seed(int(rng.integers(1, 1 << 30)))
-    if case["sample"] == drbamd.I16:
-        source = torch.randint(-32767, 32768, (n, ch, source_total + 64), device="cuda:0", dtype=torch.int16, generator=generator)
-    else:
-        source = torch.rand((n, ch, source_total + 64), device="cuda:0", generator=generator) * 2.0 - 1.0
-    width = source.shape[2]
+    interleaved = case["layout"] == drbamd.INTERLEAVED
+    width = source_total + 64
     room = target_total + 4096
-    target = torch.zeros((n, ch, room), device="cuda:0", dtype=source.dtype)
+    shape = (n, width, ch) if interleaved else (n, ch, width)
+    if case["sample"] == drbamd.I16:
+        source = torch.randint(-32767, 32768, shape, device="cuda:0", dtype=torch.int16, generator=generator)
+    else:
+        source = torch.rand(shape, device="cuda:0", generator=generator) * 2.0 - 1.0
+    target = torch.zeros((n, room, ch) if interleaved else (n, ch, room), device="cuda:0", dtype=source.dtype)
+    # (bytes from one frame to the next of a stream's buffer)
+    hop = ch if interleaved else 1
     size = source.element_size()
     batch = drbamd.Batch(config)
     stream = torch.cuda.current_stream().cuda_stream
@@ -269,8 +273,8 @@ def run_scale_case(case, plan, rng):
             other = batch.query([frames] * n)[0]
             take, make = (other, frames) if pull else (frames, other)
             produced = (ctypes.c_int * n)()
-            batch.process_dense(source.data_ptr() + size * read, ch * width, width,
-                                target.data_ptr() + size * made, ch * room, room,
+            batch.process_dense(source.data_ptr() + size * hop * read, ch * width, 0 if interleaved else width,
+                                target.data_ptr() + size * hop * made, ch * room, 0 if interleaved else room,
                                 frames, take if pull else room - made, stream=stream, produced=produced)
             if list(produced) != [other] * n:
                 return "produced %s against %d" % (list(produced)[:4], other)
@@ -279,11 +283,11 @@ def run_scale_case(case, plan, rng):
         batch.synchronize(stream)
         exact = case["arithmetic"] == "exact" or not info.fast_path
         for s in sorted(set([0, n - 1] + [int(v) for v in rng.integers(0, n, 3)])):
-            x = source[s].cpu().numpy()
+            x = np.ascontiguousarray(source[s].cpu().numpy().T) if interleaved else source[s].cpu().numpy()
             xf = x if case["sample"] == drbamd.F32 else support.oracle_convert_samples(x, "f32").reshape(x.shape)
             want_f = support.oracle_pull(plan, xf, total)[0] if pull else support.oracle_push(plan, xf[:, :total])
             want = want_f if case["sample"] == drbamd.F32 else support.oracle_convert_samples(np.ascontiguousarray(want_f), "i16").reshape(want_f.shape)
-            got = target[s, :, :made].cpu().numpy()
+            got = np.ascontiguousarray(target[s, :made, :].cpu().numpy().T) if interleaved else target[s, :, :made].cpu().numpy()
             if got.shape != want.shape:
                 return "shape %s against %s (stream %d of %d)" % (got.shape, want.shape, s, n)
             if case["sample"] == drbamd.F32:
