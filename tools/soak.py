@@ -83,6 +83,8 @@ def run_case(case, plan, rng, even):
     totals = [t // even * even for t in totals]
     runner = gpu_support.StreamRunner(config, inputs)
     left = list(totals)
+    again = int(rng.integers(0, n)) if rng.integers(0, 4) == 0 else -1   # a stream that is started over after its second step
+    taken = 0
     try:
         while any(left):
             limit = int(rng.choice([64, 700, 5000, 70000])) if most < 100000 else int(rng.choice([5000, 70000, 600000]))
@@ -91,6 +93,12 @@ def run_case(case, plan, rng, even):
                 steps = [min(l, even * 8) for l in left]
             runner.step(steps)
             left = [l - s for l, s in zip(left, steps)]
+            taken += 1
+            if taken == 2 and again >= 0:
+                runner.batch.reset(again, 1)
+                runner.read[again] = 0
+                runner.outputs[again] = []
+                left[again] = totals[again]
         for s in (range(n) if n <= 16 else sorted(int(v) for v in rng.choice(n, 16, replace=False))):
             xf = inputs[s] if case["sample"] == drbamd.F32 else support.oracle_convert_samples(inputs[s], "f32").reshape(inputs[s].shape)
             if pull:
