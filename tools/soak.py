@@ -298,6 +298,8 @@ def run_scale_case(case, plan, rng):
             got = np.ascontiguousarray(target[s, :made, :].cpu().numpy().T) if interleaved else target[s, :, :made].cpu().numpy()
             if got.shape != want.shape:
                 return "shape %s against %s (stream %d of %d)" % (got.shape, want.shape, s, n)
+            if not want.size:
+                continue   # (too few frames for one block of the slicer's)
             if case["sample"] == drbamd.F32:
                 if exact and not np.array_equal(got.view(np.uint32), want.view(np.uint32)):
                     return "stream %d of %d differs (exact)" % (s, n)
