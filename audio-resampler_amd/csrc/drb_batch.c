@@ -16,6 +16,7 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -695,6 +696,19 @@ DrbAmd_Status drb_amd_batch_create (DrbAmd_Batch_Config const * config, DrbAmd_B
         batch->launches[i].fast.tile_stride = stride ? atoi(stride) : 0;
         batch->launches[i].fast.no_carry = no_carry ? atoi(no_carry) : 0;
         batch->launches[i].fast.rebuild_tiles = getenv("DRB_AMD_FAST_REBUILD_TILES") ? atoi(getenv("DRB_AMD_FAST_REBUILD_TILES")) : 0;
+
+        /* How many tiles one coefficient set of the split kernel serves follows from how
+         * fast the fixed-point phase leaves the exact rate ratio, in source frames per
+         * segment: 44.1 <-> 48 kHz (1.7e-8, 1.9e-8) and everything slower keeps its error
+         * up to 192 tiles (tools/stretch_probe.py) and gets 128; 176.4 <-> 192 kHz
+         * (4.5e-8, 4.8e-8) loses a third of its margin from 64 to 96 and gets 32. */
+        if (batch->launches[i].fast.kind == 4 && batch->launches[i].fast.rebuild_tiles <= 0)
+        {
+            Drb_Fast_Chain const * const fast = &batch->launches[i].fast;
+            double const drift = fabs((double)((long long)fast->seg_s * fast->target_delta - (long long)fast->seg_u * fast->source_delta) * fast->scale);
+
+            batch->launches[i].fast.rebuild_tiles = drift <= 2.0e-8 ? 128 : drift >= 3.0e-8 ? 32 : 0;
+        }
         batch->launches[i].staged.ablate = batch->launches[i].fast.ablate;
         batch->launches[i].staged.tile_stride = batch->launches[i].fast.tile_stride;
         batch->launches[i].staged.no_carry = batch->launches[i].fast.no_carry;
