@@ -129,8 +129,9 @@ enum { drb_collapse_max_blocks = 12 };
  * through a tile (they share the phase, and with it the coefficients).  The drift of the fixed-point phase is not
  * folded into the coefficients: a fourth product with the coefficients'
  * derivatives is scaled per tile AND per segment by the distance from the
- * stretch's anchor, so a set serves a stretch of drb_split_stretch_tiles tiles
- * and every segment gets its own phase. */
+ * stretch's anchor, so a set serves a stretch of Drb_Fast_Chain.rebuild_tiles
+ * tiles (drb_split_stretch_tiles where that is 0) and every segment gets its
+ * own phase. */
 enum { drb_split_max_blocks = 10, drb_split_stretch_tiles = 64, drb_split_loaders = 6, drb_split_planes = 3 };
 
 typedef struct Drb_Collapse_Job

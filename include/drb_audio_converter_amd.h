@@ -291,7 +291,7 @@ extern DrbAmd_Status drb_amd_batch_process_dense
  * grow on demand, and the call makes no hipMalloc / hipFree / hipHostMalloc
  * and no host allocation either.  Limits, reported as drb_amd_error_capacity:
  * stream_count x launches per step <= 26214 (1 MiB of step descriptors);
- * stream_count x stretches of 64 tiles <= 131072; a chain of several launches
+ * stream_count x stretches of tiles (32 to 128 tiles each, by rate pair) <= 131072; a chain of several launches
  * must have run a step at least this long through drb_amd_batch_process before
  * (its buffers between launches do not grow here).  Where the streams' phases
  * differ so much that their coefficient sets exceed the workspace (about 47
