@@ -25,6 +25,7 @@ typedef struct Converter_Body
     float * device_source;        /* [channel][buffer_length / channels]        */
     float * device_target;
     long channel_capacity;        /* frames per channel in the device buffers   */
+    int warned;                   /* a sample outside fast arithmetic's range was reported */
 }
 Converter_Body;
 
@@ -232,6 +233,23 @@ static void die (char const * what)
     abort();
 }
 
+/* Waits for the sub-block.  Only fast arithmetic (DRB_AMD_ARITHMETIC=fast) can
+ * meet a sample it cannot carry; upstream converts any float, and process()
+ * has no way to refuse one, so that is said once on stderr and the stream goes on
+ * (its frames around the sample are not numbers). */
+static void settle (Converter_Body * body)
+{
+    DrbAmd_Status const status = drb_amd_batch_synchronize(body->batch, 0);
+
+    if (status == drb_amd_error_bad_argument)
+    {
+        if (!body->warned) fprintf(stderr, "drb_audio_converter_process: %s\n", drb_amd_last_error());
+
+        body->warned = 1;
+    }
+    else if (status != drb_amd_ok) die("synchronize");
+}
+
 void drb_audio_converter_process
     (
         DrB_Audio_Converter * converter, void * work_memory, double timestamp,
@@ -287,7 +305,7 @@ void drb_audio_converter_process
                 if (drb_hip_download_async(buffers[c].samples + offset, body->device_target + c * capacity, (size_t)step * sizeof(float), 0)) die("download");
             }
 
-            if (drb_amd_batch_synchronize(body->batch, 0) != drb_amd_ok) die("synchronize");
+            settle(body);
         }
         else
         {
@@ -307,7 +325,7 @@ void drb_audio_converter_process
                 if (produced > 0 && drb_hip_download_async(views[c].samples, body->device_target + c * capacity, (size_t)produced * sizeof(float), 0)) die("download");
             }
 
-            if (drb_amd_batch_synchronize(body->batch, 0) != drb_amd_ok) die("synchronize");
+            settle(body);
 
             body->callback.process(body->callback.state, stamp, views, produced);
         }

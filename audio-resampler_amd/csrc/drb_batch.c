@@ -21,6 +21,7 @@
 #include <string.h>
 
 enum { ring_slots = 4, max_step_frames = 1 << 24, fault_words = 128, host_slots = 3 };
+enum { fault_sample_range = 0x100 };   /* bit of the kernels' fault word: see fetch_fault */
 
 enum { max_launches = drb_max_stages };
 
@@ -1619,7 +1620,27 @@ static DrbAmd_Status fetch_fault (DrbAmd_Batch * batch, void * hip_stream)
 
     if (!code) code = drb_hip_stream_synchronize(hip_stream);
     if (code) return fail_hip("hipStreamSynchronize", code);
-    if (*batch->fault_host) return fail(drb_amd_error_device, "kernel range check failed (code %d)", *batch->fault_host);
+
+    int const fault = *batch->fault_host;
+
+    /* A sample that fast arithmetic's pairs of halves cannot carry (beyond +-65519,
+     * infinite or not a number) is the caller's data, not a broken kernel: the
+     * bit is reported once and cleared, the batch stays usable (the stream that
+     * held the sample has it in its history until enough frames have followed;
+     * drb_amd_batch_reset clears that too). */
+    if (fault & fault_sample_range)
+    {
+        *batch->fault_host = fault & ~fault_sample_range;
+
+        code = drb_hip_upload_async(batch->fault_device, batch->fault_host, sizeof(int), hip_stream);
+
+        if (!code) code = drb_hip_stream_synchronize(hip_stream);
+        if (code) return fail_hip("hipStreamSynchronize", code);
+
+        if (!(fault & ~fault_sample_range)) return fail(drb_amd_error_bad_argument, "sample outside fast arithmetic's range (beyond +-65519, infinite or not a number)");
+    }
+
+    if (fault & ~fault_sample_range) return fail(drb_amd_error_device, "kernel range check failed (code %d)", fault & ~fault_sample_range);
 
     return drb_amd_ok;
 }

@@ -101,6 +101,9 @@ typedef struct Drb_Fast_Chain
     int apart_stride;                       /* kind 4: 0: a plane is a straight copy of the source (odd segment lengths);
                                                else every segment's rows have a stretch of their own, this many (an odd
                                                number of) words apart                                                        */
+    int image_seg;                          /* kind 4: words from one segment's target frames to the next's in the
+                                               images of a tile's results in LDS (seg_y, or a few more so that the
+                                               four groups of a wave's lanes write to different banks)                */
     int lds_floats;
     int tile_frames;                        /* target frames per tile = 15 * seg_y    */
     long long source_delta, target_delta;

@@ -1161,13 +1161,22 @@ int drb_plan_split_geometry (Drb_Fast_Chain * chain, int lds_budget_bytes)
         c.plane_words = 16 * c.apart_stride;
     }
 
+    /* The images of a tile's results: a lane writes one target frame of four
+     * segments, the four groups of lanes 4 segments apart.  With the segments
+     * 4 (mod 8) words apart, two groups share a bank at most (which a 32-bit
+     * store does not notice).  Segments of whole 16-byte runs only: a lane of the
+     * waves that store a tile reads four consecutive frames as one run. */
+    c.image_seg = c.seg_y;
+
+    if ((c.seg_y & 3) == 0) while ((c.image_seg & 7) != 4) c.image_seg += 4;
+
     /* planes [3][channels of a workgroup], then two images [channels] of a tile's
      * target frames; a workgroup takes both channels of an interleaved stereo
      * stream, else one channel */
     int const together = c.layout == 1 && c.channels == 2 ? 2 : 1;
 
     c.off_x = 0;
-    c.lds_floats = drb_split_planes * together * c.plane_words + 2 * together * 16 * c.seg_y;
+    c.lds_floats = drb_split_planes * together * c.plane_words + 2 * together * 16 * c.image_seg;
 
     if (c.lds_floats * 4 > lds_budget_bytes) return 0;
 

@@ -3,6 +3,8 @@
 Bound from the task statement: float32 within 1e-5 relative / 1e-6 absolute of
 the upstream C implementation (|got - want| <= 1e-6 + 1e-5 |want|) on inputs in
 [-1, 1]; integer outputs within +-1 LSB."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -282,3 +284,58 @@ def test_fast_mode_one_long_step_of_few_streams_on_the_staged_kernels(src, dst, 
         assert got.shape == want.shape
         assert assert_close(got, want, "stream %d" % s) < 9e-7
     runner.close()
+
+
+@pytest.mark.parametrize("bad", [1.0e5, -7.0e4, float("inf"), float("nan")], ids=["1e5", "-7e4", "inf", "nan"])
+def test_fast_mode_reports_samples_its_halves_cannot_carry(bad):
+    """Upstream takes any float (drb-audio-converter.h:87-91); fast arithmetic
+    carries a sample as two halves, which end at +-65504.  A sample beyond that
+    (or an infinite one, or a NaN) in one stream of a batch: synchronize says so,
+    once, the other streams are within the bound, and the batch goes on working.
+    Exact arithmetic takes the same data and equals upstream's scalar build
+    wherever that is a number (bit for bit), and is no number where it is none."""
+    ch, frames, n = 2, 60000, 3
+    status, plan = support.oracle_plan(44100, 48000, ch, 256, 16, PUSH, support.GOOD)
+    assert status == 1
+    inputs = [support.white_noise(ch, 2 * frames, 900 + s) for s in range(n)]
+    inputs[1][1, 31234] = bad
+    for arithmetic in (drbamd.FAST, drbamd.EXACT):
+        config = drbamd.make_config(44100, 48000, ch, 256, 16, PUSH, support.GOOD, arithmetic=arithmetic, streams=n)
+        batch = drbamd.Batch(config)
+        source = torch.from_numpy(np.stack(inputs)).cuda()
+        capacity = batch.query([2 * frames] * n)[0] + 4096
+        target = torch.zeros((n, ch, capacity), device="cuda:0")
+        stream = torch.cuda.current_stream().cuda_stream
+        counts = (ctypes.c_int * n)()
+        batch.process_dense(source.data_ptr(), ch * 2 * frames, 2 * frames, target.data_ptr(), ch * capacity, capacity,
+                            frames, capacity, stream=stream, produced=counts)
+        made = counts[0]
+        if arithmetic == drbamd.FAST:
+            with pytest.raises(drbamd.DrbError) as error:
+                batch.synchronize(stream)
+            assert error.value.status == "bad_argument" and "range" in str(error.value)
+            batch.synchronize(stream)   # reported once
+        else:
+            batch.synchronize(stream)
+        # a second step, of good samples only (the bad one is 28 766 frames back: out of every window)
+        batch.process_dense(source.data_ptr() + 4 * frames, ch * 2 * frames, 2 * frames,
+                            target.data_ptr() + 4 * made, ch * capacity, capacity,
+                            frames, capacity - made, stream=stream, produced=counts)
+        batch.synchronize(stream)
+        made += counts[0]
+        got = target.cpu().numpy()
+        for s in range(n):
+            want = support.oracle_push(plan, inputs[s])
+            assert want.shape[1] == made
+            numbers = np.isfinite(want)
+            if arithmetic == drbamd.EXACT:
+                assert np.array_equal(got[s, :, :made].view(np.uint32)[numbers], want.view(np.uint32)[numbers])
+                assert not np.isfinite(got[s, :, :made][~numbers]).any()
+            elif s != 1:
+                assert numbers.all()
+                assert_close(got[s, :, :made], want, "stream %d" % s)
+            else:
+                # the stream with the bad sample: right again once the sample has left every window
+                tail = slice(frames * 48000 // 44100 + 2048, made)
+                assert_close(got[s, :, tail], want[:, tail], "stream 1 behind the bad sample")
+        batch.close()
