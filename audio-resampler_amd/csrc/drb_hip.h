@@ -99,8 +99,8 @@ typedef struct Drb_Fast_Chain
     int chunks;                             /* kind 4: 32-frame steps of a row block's window (3 or 4)                      */
     int plane_words;                        /* kind 4: words of one channel's source plane in LDS                           */
     int apart_stride;                       /* kind 4: 0: a plane is a straight copy of the source (odd segment lengths);
-                                               else every segment's rows have a stretch of their own, this many (an odd
-                                               number of) words apart                                                        */
+                                               else seg_x + 1: a word of padding in front of every segment but the first,
+                                               so that the segments start an odd number of words apart                      */
     int image_seg;                          /* kind 4: words from one segment's target frames to the next's in the
                                                images of a tile's results in LDS (seg_y, or a few more so that the
                                                four groups of a wave's lanes write to different banks)                */

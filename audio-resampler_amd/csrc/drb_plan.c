@@ -1146,8 +1146,10 @@ int drb_plan_split_geometry (Drb_Fast_Chain * chain, int lds_budget_bytes)
 
     /* The 16 columns of an operand read must fall into 16 different LDS banks: they
      * do where the segments lie an odd number of words apart.  A straight copy of
-     * the source has them seg_x apart; for even seg_x every segment's rows get a
-     * stretch of their own instead, an odd number of words from the next. */
+     * the source has them seg_x apart; for even seg_x the plane has a word of
+     * padding in front of every segment but the first, seg_x + 1 words from
+     * segment to segment.  A window that runs across the padding has a zero
+     * coefficient there and one frame less: it may cross one padding only. */
     if (c.seg_x & 1)
     {
         c.apart_stride = 0;
@@ -1155,10 +1157,10 @@ int drb_plan_split_geometry (Drb_Fast_Chain * chain, int lds_budget_bytes)
     }
     else
     {
-        if (c.plane_rows > 2 * c.seg_x) return 0;   /* the loaders write a source frame to two segments' rows at most */
+        if (c.plane_rows > 2 * c.seg_x || c.window > 32 * c.chunks - 1) return 0;
 
-        c.apart_stride = (c.plane_rows + 4) | 1;
-        c.plane_words = 16 * c.apart_stride;
+        c.apart_stride = c.seg_x + 1;
+        c.plane_words = (16 * c.apart_stride + c.plane_rows - c.seg_x + 8 + 3) / 4 * 4;
     }
 
     /* The images of a tile's results: a lane writes one target frame of four
@@ -1229,7 +1231,8 @@ int drb_plan_collapse_job (Drb_Fast_Chain const * chain, long long rest, int par
 
         job->first_row[b] = start < last_start ? start : last_start;
 
-        if (job->first_row[b] < 0 || hi[b] - lo[b] > 4 * chain->ksteps) return 0;
+        /* (a padded plane's window gives one slot to the padding) */
+        if (job->first_row[b] < 0 || hi[b] - lo[b] > 4 * chain->ksteps - (chain->apart_stride ? 1 : 0)) return 0;
     }
 
     return 1;
