@@ -1159,8 +1159,11 @@ int drb_plan_split_geometry (Drb_Fast_Chain * chain, int lds_budget_bytes)
     {
         if (c.plane_rows > 2 * c.seg_x || c.window > 32 * c.chunks - 1) return 0;
 
+        /* (every frame of a tile's loads is written: 36 words in front of segment 0's
+         * row 0 for the up to 31 frames the loads begin in front of it, a word of
+         * padding for each of the up to 20 segments they reach, see drb_split.inc) */
         c.apart_stride = c.seg_x + 1;
-        c.plane_words = (16 * c.apart_stride + c.plane_rows - c.seg_x + 8 + 3) / 4 * 4;
+        c.plane_words = (36 + c.plane_stride + 20 + 3) / 4 * 4;
     }
 
     /* The images of a tile's results: a lane writes one target frame of four
