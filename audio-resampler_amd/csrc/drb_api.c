@@ -15,6 +15,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* host allocations are counted with the device's (drb_hip_allocation_calls) */
+static void * counted_calloc (size_t count, size_t size) { drb_hip_count_allocation(); return calloc(count, size); }
+static void counted_free (void * pointer) { if (pointer) drb_hip_count_allocation(); free(pointer); }
+
 typedef struct Converter_Body
 {
     struct Converter_Body * next;
@@ -49,7 +53,7 @@ static void free_body (Converter_Body * body)
     if (body->device_source) drb_hip_free(body->device_source);
     if (body->device_target) drb_hip_free(body->device_target);
     if (body->batch) drb_amd_batch_destroy(body->batch);
-    free(body);
+    counted_free(body);
 }
 
 static void release_all (void)
@@ -125,14 +129,14 @@ DrB_Audio_Converter * drb_audio_converter_construct
     /* a converter constructed earlier in the same memory is replaced */
     unregister_owner(memory);
 
-    Converter_Body * const body = calloc(1, sizeof(*body));
+    Converter_Body * const body = counted_calloc(1, sizeof(*body));
 
     if (!body) return 0;
 
     if (drb_plan_resolve(source_sampling_rate, target_sampling_rate, channel_count, block_size,
                          max_block_count, direction, resampling_quality, &body->plan) != 1)
     {
-        free(body);
+        counted_free(body);
         return 0;
     }
 
@@ -157,7 +161,7 @@ DrB_Audio_Converter * drb_audio_converter_construct
     if (drb_amd_batch_create(&config, &body->batch) != drb_amd_ok)
     {
         fprintf(stderr, "drb_audio_converter_construct: %s\n", drb_amd_last_error());
-        free(body);
+        counted_free(body);
         return 0;
     }
 

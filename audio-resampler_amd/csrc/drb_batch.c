@@ -20,12 +20,30 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* host allocations are counted with the device's (drb_hip_allocation_calls) */
+static void * counted_calloc (size_t count, size_t size) { drb_hip_count_allocation(); return calloc(count, size); }
+static void * counted_malloc (size_t size) { drb_hip_count_allocation(); return malloc(size); }
+static void counted_free (void * pointer) { if (pointer) drb_hip_count_allocation(); free(pointer); }
+
 enum { ring_slots = 4, max_step_frames = 1 << 24, fault_words = 128, host_slots = 3 };
 enum { fault_sample_range = 0x100 };   /* bit of the kernels' fault word: see fetch_fault */
 
 enum { max_launches = drb_max_stages };
 
-static size_t const collapse_set_bytes_limit = (size_t)1 << 30;   /* of coefficient sets per step */
+static size_t const collapse_set_bytes_limit = (size_t)1 << 30;   /* of coefficient sets at a time */
+
+/* Where the distinct phases of a step need more coefficient sets than that (or
+ * than the static workspace holds), the step's streams are dealt with in groups,
+ * one after the other on the step's HIP stream: the sets of a group are built,
+ * its streams filtered, then the next group's sets take their place. */
+enum { max_groups = 256 };
+
+typedef struct Collapse_Group
+{
+    int first_stream, stream_count;
+    int first_job, job_count;         /* in the step's job table; a stretch's job index counts from first_job */
+}
+Collapse_Group;
 static size_t const static_host_bytes = (size_t)256 << 10;       /* pinned, per ring slot, from creation on */
 
 typedef struct Fast_Launch
@@ -100,6 +118,10 @@ struct DrbAmd_Batch
     size_t collapse_host_bytes [ring_slots];
     int * collapse_hash;                       /* host scratch                 */
     size_t collapse_hash_room;
+    Collapse_Group groups [max_groups];        /* of the step at hand          */
+    int group_count;
+    size_t set_bytes_limit;                    /* collapse_set_bytes_limit, or DRB_AMD_SET_BYTES_LIMIT (diagnostic) */
+    int wish_apart;                            /* DRB_AMD_FAST_APART (diagnostic): 1 always the staged kernels, 0 never, -1 unset */
 
     int timing;                       /* bracket the cascade kernel with events */
     void * kernel_start, * kernel_stop;
@@ -505,7 +527,7 @@ DrbAmd_Status drb_amd_plan_info (DrbAmd_Batch_Config const * config, DrbAmd_Plan
     info->bytes_per_output_sample =
         sample_bytes * ((double)plan.source_rate / plan.target_rate) + sample_bytes;
 
-    Fast_Launch * const launches = calloc(max_launches, sizeof(Fast_Launch));
+    Fast_Launch * const launches = counted_calloc(max_launches, sizeof(Fast_Launch));
 
     if (!launches) return fail(drb_amd_error_out_of_memory, "out of host memory");
 
@@ -536,7 +558,7 @@ DrbAmd_Status drb_amd_plan_info (DrbAmd_Batch_Config const * config, DrbAmd_Plan
         snprintf(info->kernel_name, sizeof(info->kernel_name), "%s", name);
     }
 
-    free(launches);
+    counted_free(launches);
 
     return drb_amd_ok;
 }
@@ -616,7 +638,7 @@ static void release (DrbAmd_Batch * batch)
     if (batch->collapse_jobs) drb_hip_free(batch->collapse_jobs);
     if (batch->collapse_spots) drb_hip_free(batch->collapse_spots);
     if (batch->collapse_sets) drb_hip_free(batch->collapse_sets);
-    free(batch->collapse_hash);
+    counted_free(batch->collapse_hash);
 
     if (batch->kernel_start) drb_hip_event_destroy(batch->kernel_start);
     if (batch->kernel_stop) drb_hip_event_destroy(batch->kernel_stop);
@@ -628,16 +650,16 @@ static void release (DrbAmd_Batch * batch)
     if (batch->fault_device) drb_hip_free(batch->fault_device);
     if (batch->fault_host) drb_hip_host_free(batch->fault_host);
 
-    free(batch->states);
-    free(batch->trial_states);
-    free(batch->steps);
-    free(batch->dense_source);
-    free(batch->dense_target);
-    free(batch->dense_frames);
-    free(batch->dense_capacity);
-    free(batch->dense_produced);
-    free(batch->feed_counts);
-    free(batch);
+    counted_free(batch->states);
+    counted_free(batch->trial_states);
+    counted_free(batch->steps);
+    counted_free(batch->dense_source);
+    counted_free(batch->dense_target);
+    counted_free(batch->dense_frames);
+    counted_free(batch->dense_capacity);
+    counted_free(batch->dense_produced);
+    counted_free(batch->feed_counts);
+    counted_free(batch);
 }
 
 DrbAmd_Status drb_amd_batch_create (DrbAmd_Batch_Config const * config, DrbAmd_Batch ** out)
@@ -667,7 +689,7 @@ DrbAmd_Status drb_amd_batch_create (DrbAmd_Batch_Config const * config, DrbAmd_B
     if (!is_gfx950) return fail(drb_amd_error_no_device, "device %d is not gfx950; this library carries gfx950 code only", device);
     if ((code = drb_hip_set_device(device)) != 0) return fail_hip("hipSetDevice", code);
 
-    DrbAmd_Batch * const batch = calloc(1, sizeof(*batch));
+    DrbAmd_Batch * const batch = counted_calloc(1, sizeof(*batch));
 
     if (!batch) return fail(drb_amd_error_out_of_memory, "out of host memory");
 
@@ -686,6 +708,14 @@ DrbAmd_Status drb_amd_batch_create (DrbAmd_Batch_Config const * config, DrbAmd_B
     if (batch->launch_count > 0) batch->launches[0].fast.history = batch->launches[0].staged.history = batch->geometry.history_frames;
 
     /* timing diagnostics only: skip phases of the fast kernel (results are wrong) */
+    {
+        char const * const limit = getenv("DRB_AMD_SET_BYTES_LIMIT"), * const wish = getenv("DRB_AMD_FAST_APART");
+
+        batch->set_bytes_limit = limit && atoll(limit) > 0 ? (size_t)atoll(limit) : collapse_set_bytes_limit;
+        batch->wish_apart = wish ? atoi(wish) : -1;
+        batch->group_count = 1;
+    }
+
     char const * const ablate = getenv("DRB_AMD_FAST_ABLATE");
 
     char const * const stride = getenv("DRB_AMD_FAST_TILE_STRIDE");
@@ -719,15 +749,15 @@ DrbAmd_Status drb_amd_batch_create (DrbAmd_Batch_Config const * config, DrbAmd_B
 
     size_t const n = (size_t)config->stream_count;
 
-    batch->states = calloc(n, sizeof(Drb_Stream_State));
-    batch->trial_states = calloc(n, sizeof(Drb_Stream_State));
-    batch->steps = calloc(n, sizeof(Drb_Step));
-    batch->dense_source = calloc(n, sizeof(void *));
-    batch->dense_target = calloc(n, sizeof(void *));
-    batch->dense_frames = calloc(n, sizeof(int));
-    batch->dense_capacity = calloc(n, sizeof(int));
-    batch->dense_produced = calloc(n, sizeof(int));
-    batch->feed_counts = calloc(n, sizeof(int));
+    batch->states = counted_calloc(n, sizeof(Drb_Stream_State));
+    batch->trial_states = counted_calloc(n, sizeof(Drb_Stream_State));
+    batch->steps = counted_calloc(n, sizeof(Drb_Step));
+    batch->dense_source = counted_calloc(n, sizeof(void *));
+    batch->dense_target = counted_calloc(n, sizeof(void *));
+    batch->dense_frames = counted_calloc(n, sizeof(int));
+    batch->dense_capacity = counted_calloc(n, sizeof(int));
+    batch->dense_produced = counted_calloc(n, sizeof(int));
+    batch->feed_counts = counted_calloc(n, sizeof(int));
 
     if (!batch->states || !batch->trial_states || !batch->steps || !batch->dense_source
         || !batch->dense_target || !batch->dense_frames || !batch->dense_capacity || !batch->dense_produced
@@ -773,12 +803,17 @@ DrbAmd_Status drb_amd_batch_create (DrbAmd_Batch_Config const * config, DrbAmd_B
 
         while (hash_size < 16 * n + 2) hash_size *= 2;
 
-        batch->collapse_hash = malloc(hash_size * sizeof(int));
+        batch->collapse_hash = counted_malloc(hash_size * sizeof(int));
         batch->collapse_hash_room = batch->collapse_hash ? hash_size : 0;
     }
 
-    /* the static workspace's address on this GPU (looked up once per device) */
-    if (!code) code = drb_hip_static_workspace(device, &batch->static_base, &batch->static_bytes);
+    /* the static workspace's address on this GPU (looked up once per device); a
+     * failure here only concerns drb_amd_batch_process_dense_static, which reports it */
+    if (!code && drb_hip_static_workspace(device, &batch->static_base, &batch->static_bytes) != 0)
+    {
+        batch->static_base = 0;
+        batch->static_bytes = 0;
+    }
 
     if (!code) code = drb_hip_memset_async(batch->fault_device, 0, fault_words * sizeof(long long), 0);
 
@@ -970,8 +1005,8 @@ static DrbAmd_Status collapse_prepare
     {
         if (batch->no_alloc) return fail(drb_amd_error_capacity, "too many stretches for the tables the batch was created with");
 
-        free(batch->collapse_hash);
-        batch->collapse_hash = malloc(hash_size * sizeof(int));
+        counted_free(batch->collapse_hash);
+        batch->collapse_hash = counted_malloc(hash_size * sizeof(int));
         batch->collapse_hash_room = batch->collapse_hash ? hash_size : 0;
 
         if (!batch->collapse_hash) return fail(drb_amd_error_out_of_memory, "out of host memory");
@@ -981,7 +1016,14 @@ static DrbAmd_Status collapse_prepare
 
     Drb_Collapse_Spot * const spots = batch->collapse_host[slot];
     Drb_Collapse_Job * const jobs = (Drb_Collapse_Job *)((char *)batch->collapse_host[slot] + spots_bytes);
-    int job_count = 0;
+    int job_count = 0, most_jobs = 0;
+    size_t const set_bytes = (size_t)drb_hip_collapse_set_words(fast) * sizeof(unsigned int);
+    size_t const limit = batch->no_alloc ? batch->collapse_sets_room * sizeof(unsigned int) : batch->set_bytes_limit;
+    Collapse_Group * group = &batch->groups[0];
+
+    batch->group_count = 1;
+    group->first_stream = 0;
+    group->first_job = 0;
 
     for (int s = 0; s < n; s++)
     {
@@ -990,9 +1032,10 @@ static DrbAmd_Status collapse_prepare
         int const tiles = (call->target_frames + fast->tile_frames - 1) / fast->tile_frames;
         int const stretches = (tiles + wanted - 1) / wanted;
         int const every = wanted;   /* a fixed length: streams of one phase share sets whatever their lengths */
+        int const jobs_before = job_count;
 
         /* streams that run in step: the same stretches */
-        if (s > 0 && call->phase == call[-1].phase && call->delay == call[-1].delay
+        if (s > group->first_stream && call->phase == call[-1].phase && call->delay == call[-1].delay
             && call->target_frames == call[-1].target_frames)
         {
             memcpy(row, row - max_stretches, (size_t)max_stretches * sizeof(Drb_Collapse_Spot));
@@ -1025,13 +1068,34 @@ static DrbAmd_Status collapse_prepare
             {
                 /* A set per phase and stretch: with very many phases apart (thousands of
                  * streams, each cut differently) the sets would outweigh the samples.
-                 * Such a step runs the three stages apart, which need no sets. */
-                size_t const limit = batch->no_alloc ? batch->collapse_sets_room * sizeof(unsigned int) : collapse_set_bytes_limit;
-
-                if (((size_t)job_count + 2) * (size_t)drb_hip_collapse_set_words(fast) * sizeof(unsigned int) > limit)
+                 * Such a step runs the three stages apart, which need no sets; a chain
+                 * that has no such kernels goes on with this stream in a group of its own. */
+                if (((size_t)(job_count - group->first_job) + 2) * set_bytes > limit)
                 {
-                    *too_many_out = 1;
-                    return drb_amd_ok;
+                    if (launch->has_staged)
+                    {
+                        *too_many_out = 1;
+                        return drb_amd_ok;
+                    }
+
+                    if (s == group->first_stream || batch->group_count == max_groups)
+                    {
+                        return fail(drb_amd_error_capacity, "stream %d: the coefficient sets of this step do not fit %s", s,
+                                    batch->no_alloc ? "the static workspace" : "their memory");
+                    }
+
+                    /* the group ends in front of this stream, which starts the next one over */
+                    job_count = jobs_before;
+                    group->stream_count = s - group->first_stream;
+                    group->job_count = job_count - group->first_job;
+                    if (group->job_count > most_jobs) most_jobs = group->job_count;
+
+                    group = &batch->groups[batch->group_count++];
+                    group->first_stream = s;
+                    group->first_job = job_count;
+                    memset(batch->collapse_hash, 0, hash_size * sizeof(int));
+                    s -= 1;
+                    goto next_stream;
                 }
 
                 if (!drb_plan_collapse_job(fast, rest, parity, &jobs[job_count]))
@@ -1047,15 +1111,21 @@ static DrbAmd_Status collapse_prepare
 
             if (base < -0x40000000LL || base > 0x40000000LL) return fail(drb_amd_error_bad_argument, "stream %d: step too long", s);
 
-            row[j].job = found;
+            row[j].job = found - group->first_job;
             row[j].base_x = (int)base;
         }
+
+      next_stream: ;
     }
+
+    group->stream_count = n - group->first_stream;
+    group->job_count = job_count - group->first_job;
+    if (group->job_count > most_jobs) most_jobs = group->job_count;
 
     code = collapse_grow_device((void **)&batch->collapse_spots, &batch->collapse_spots_room, (size_t)n * max_stretches, sizeof(Drb_Collapse_Spot), hip_stream, !batch->no_alloc);
     if (!code) code = collapse_grow_device((void **)&batch->collapse_jobs, &batch->collapse_jobs_room, (size_t)job_count + 1, sizeof(Drb_Collapse_Job), hip_stream, !batch->no_alloc);
     if (!code) code = collapse_grow_device((void **)&batch->collapse_sets, &batch->collapse_sets_room,
-                                           ((size_t)job_count + 1) * (size_t)drb_hip_collapse_set_words(fast), sizeof(unsigned int), hip_stream, !batch->no_alloc);
+                                           ((size_t)most_jobs + 1) * (size_t)drb_hip_collapse_set_words(fast), sizeof(unsigned int), hip_stream, !batch->no_alloc);
 
     if (code == code_no_room) return fail(drb_amd_error_capacity, "the step's coefficient tables do not fit the static workspace");
     if (code) return fail(drb_amd_error_out_of_memory, "coefficient sets: %s", drb_hip_error_text(code));
@@ -1220,9 +1290,7 @@ DrbAmd_Status drb_amd_batch_process
 
         if (fast && batch->launches[l].fast.kind >= 3)
         {
-            char const * const limit = getenv("DRB_AMD_FAST_APART");   /* diagnostic: 1 = always */
-
-            if (limit && atoi(limit) == 1 && batch->launches[l].has_staged) { apart[l] = 1; continue; }
+            if (batch->wish_apart == 1 && batch->launches[l].has_staged) { apart[l] = 1; continue; }
 
             /* A step of a tile or two per stream (calls of a few thousand frames) is all
              * set-up: the staged kernels need no coefficient sets built and uploaded
@@ -1230,7 +1298,7 @@ DrbAmd_Status drb_amd_batch_process
              * kernel's one workgroup per CU starts and drains alone.  Measured on
              * 4096-frame calls of 1024 streams: 0.117 against 0.141 ms of device time
              * per call, 0.108 against 0.157 ms of host time. */
-            if (batch->launches[l].has_staged && !(limit && atoi(limit) == 0))
+            if (batch->launches[l].has_staged && batch->wish_apart != 0)
             {
                 Drb_Device_Call const * const row = calls + (size_t)l * n;
                 long long most_frames = 0;
@@ -1244,7 +1312,6 @@ DrbAmd_Status drb_amd_batch_process
                                                           &collapse_stretches, &collapse_job_count, &apart[l]);
 
             if (status != drb_amd_ok) return status;
-            if (apart[l] && !batch->launches[l].has_staged) return fail(drb_amd_error_out_of_memory, "too many different phases for coefficient sets");
         }
     }
 
@@ -1274,7 +1341,7 @@ DrbAmd_Status drb_amd_batch_process
      * was measured far slower: every cross-stream wait cost most of a millisecond) */
     for (int l = 0; l < launches && !code; l++)
     {
-        if (fast && batch->launches[l].fast.kind >= 3 && !apart[l])
+        if (fast && batch->launches[l].fast.kind >= 3 && !apart[l] && batch->group_count == 1)
         {
             code = drb_hip_launch_collapse_build(&batch->launches[l].fast, batch->collapse_jobs, collapse_job_count,
                                                  batch->collapse_sets, batch->fault_device, hip_stream);
@@ -1296,13 +1363,28 @@ DrbAmd_Status drb_amd_batch_process
 
             if (shape->kind >= 3)
             {
-                code = drb_hip_launch_collapsed
-                (
-                    shape, launch_calls, n, (int)((most[l] + fast_tile - 1) / fast_tile),
-                    l == 0 ? history_in : launch->history[current], source_stride, target_stride,
-                    batch->collapse_jobs, batch->collapse_spots, collapse_stretches, batch->collapse_sets,
-                    batch->fault_device, hip_stream
-                );
+                /* (several groups: a group's sets are built where the last group's were, behind its filter kernel) */
+                for (int g = 0; g < batch->group_count && !code; g++)
+                {
+                    Collapse_Group const * const group = &batch->groups[g];
+                    float const * const past = (l == 0 ? history_in : launch->history[current])
+                                             + (size_t)group->first_stream * shape->channels * shape->history;
+
+                    if (batch->group_count > 1)
+                    {
+                        code = drb_hip_launch_collapse_build(shape, batch->collapse_jobs + group->first_job, group->job_count,
+                                                             batch->collapse_sets, batch->fault_device, hip_stream);
+                    }
+
+                    if (!code) code = drb_hip_launch_collapsed
+                    (
+                        shape, launch_calls + group->first_stream, group->stream_count, (int)((most[l] + fast_tile - 1) / fast_tile),
+                        past, source_stride, target_stride,
+                        batch->collapse_jobs + group->first_job,
+                        batch->collapse_spots + (size_t)group->first_stream * collapse_stretches, collapse_stretches,
+                        batch->collapse_sets, batch->fault_device, hip_stream
+                    );
+                }
             }
             else code = drb_hip_launch_fast
             (
@@ -1450,11 +1532,21 @@ DrbAmd_Status drb_amd_batch_process_dense_static
     batch->collapse_sets_room = (batch->static_bytes - fixed) / sizeof(unsigned int);
     batch->no_alloc = 1;
 
-    DrbAmd_Status const status = drb_amd_batch_process_dense
+    /* another batch's static step on another stream of this GPU may still be reading the workspace */
+    int code = drb_hip_set_device(batch->device);
+
+    if (!code) code = drb_hip_static_workspace_enter(batch->device, hip_stream);
+
+    DrbAmd_Status status = code ? fail_hip("static workspace", code) : drb_amd_batch_process_dense
     (
         batch, source_base, source_stream_stride, source_channel_stride,
         target_base, target_stream_stride, target_channel_stride, frames, capacity, produced_each, hip_stream
     );
+
+    if (!code && (code = drb_hip_static_workspace_leave(batch->device, hip_stream)) != 0 && status == drb_amd_ok)
+    {
+        status = fail_hip("static workspace", code);
+    }
 
     batch->no_alloc = 0;
     batch->calls_device = own_calls;
@@ -1701,6 +1793,16 @@ DrbAmd_Status drb_amd_batch_step_ms (DrbAmd_Batch * batch, float * milliseconds)
     if (code) return fail_hip("hipEventElapsedTime", code);
 
     return drb_amd_ok;
+}
+
+long long drb_amd_allocation_calls (void)
+{
+    return drb_hip_allocation_calls();
+}
+
+int drb_amd_batch_step_groups (DrbAmd_Batch const * batch)
+{
+    return batch ? batch->group_count : 0;
 }
 
 #ifdef DRB_FAST_STAMPS

@@ -163,6 +163,16 @@ int drb_hip_device_is_gfx950 (int device, int * yes, int * lds_bytes_per_block);
 /* The library's static device workspace on `device` (which must be the calling
  * thread's current device): its address there and its size.  Allocates nothing. */
 int drb_hip_static_workspace (int device, void ** pointer, size_t * bytes);
+/* Brackets of a step that keeps its tables there: every batch of a GPU shares the
+ * workspace, so a step on another stream than the last one's waits for that one
+ * (an event that exists since the look-up: no allocation here either). */
+int drb_hip_static_workspace_enter (int device, void * stream);
+int drb_hip_static_workspace_leave (int device, void * stream);
+/* How often the library has allocated or freed so far: device or pinned memory,
+ * streams and events through the functions below, host memory through
+ * drb_hip_count_allocation (which the host files call beside malloc and free). */
+long long drb_hip_allocation_calls (void);
+void drb_hip_count_allocation (void);
 int drb_hip_alloc (void ** pointer, size_t bytes);
 int drb_hip_free (void * pointer);
 int drb_hip_host_alloc (void ** pointer, size_t bytes);

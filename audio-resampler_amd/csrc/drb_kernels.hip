@@ -17,6 +17,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <mutex>
 
 #include "drb_hip.h"
@@ -41,7 +42,10 @@ __device__ inline float const * table_at (int float_offset)
     return reinterpret_cast<float const *>(drb_table_words) + float_offset;
 }
 
-// One rounding per operation, whatever the contraction flags say.
+// One rounding per operation: the scalar helpers below say so by construction
+// (__fmul_rn / __fadd_rn), whatever the contraction flags; the packed two-channel
+// arithmetic of the fractional stage is plain vector code, kept from being
+// fused by the pragma in front of it (and by -ffp-contract=off in the Makefile).
 typedef float float2_t __attribute__((ext_vector_type(2)));
 
 __device__ inline float mul (float a, float b) { return __fmul_rn(a, b); }
@@ -307,6 +311,9 @@ __device__ void stage_sinc
         int first_output, int outputs, int in_origin, float const * bank
     )
 {
+    // (p + x * k below must stay a rounded product and a rounded sum, as upstream's)
+    #pragma clang fp contract(off)
+
     constexpr int kRows = CUBIC ? 4 : 2;
     constexpr int kStride = TAPS + 1;
     double const bank_scale = CUBIC ? 29.0 : 63.0;
@@ -676,6 +683,12 @@ constexpr int kScratchDevices = 64;
 static __device__ __align__(256) unsigned char scratch [kScratchBytes];
 
 static void * scratch_address [kScratchDevices];
+// The last step that used a device's workspace: an event recorded behind it (created
+// with the address, so that a step creates nothing), and the stream it ran on.  A
+// step on another stream waits for that event before it rewrites the workspace.
+static hipEvent_t scratch_event [kScratchDevices];
+static void * scratch_stream [kScratchDevices];
+static bool scratch_used [kScratchDevices];
 static std::mutex scratch_lock;
 
 // ---- C ABI --------------------------------------------------------------------
@@ -692,10 +705,14 @@ int drb_hip_static_workspace (int device, void ** pointer, size_t * bytes)
     if (!scratch_address[device])
     {
         void * address = nullptr;
-        hipError_t const status = hipGetSymbolAddress(&address, HIP_SYMBOL(scratch));
+        hipError_t status = hipGetSymbolAddress(&address, HIP_SYMBOL(scratch));
 
         if (status != hipSuccess) return status;
         if (!address) return hipErrorInvalidSymbol;
+
+        status = hipEventCreateWithFlags(&scratch_event[device], hipEventDisableTiming);
+
+        if (status != hipSuccess) return status;
 
         scratch_address[device] = address;
     }
@@ -704,6 +721,37 @@ int drb_hip_static_workspace (int device, void ** pointer, size_t * bytes)
     *bytes = kScratchBytes;
 
     return 0;
+}
+
+// Brackets of a step that keeps its tables in the workspace.  Every batch of a
+// GPU shares the one workspace: `enter` makes `stream` wait for the last such
+// step if that ran on another stream (on the same stream the order of the
+// launches already keeps them apart), `leave` marks the end of this one.
+// Neither allocates.
+int drb_hip_static_workspace_enter (int device, void * stream)
+{
+    if (device < 0 || device >= kScratchDevices || !scratch_address[device]) return hipErrorInvalidDevice;
+
+    std::lock_guard<std::mutex> guard(scratch_lock);
+
+    if (scratch_used[device] && scratch_stream[device] != stream)
+    {
+        return hipStreamWaitEvent(static_cast<hipStream_t>(stream), scratch_event[device], 0);
+    }
+
+    return 0;
+}
+
+int drb_hip_static_workspace_leave (int device, void * stream)
+{
+    if (device < 0 || device >= kScratchDevices || !scratch_address[device]) return hipErrorInvalidDevice;
+
+    std::lock_guard<std::mutex> guard(scratch_lock);
+
+    scratch_used[device] = true;
+    scratch_stream[device] = stream;
+
+    return hipEventRecord(scratch_event[device], static_cast<hipStream_t>(stream));
 }
 
 int drb_hip_device_count (int * count) { return hipGetDeviceCount(count); }
@@ -727,10 +775,18 @@ int drb_hip_device_is_gfx950 (int device, int * yes, int * lds_bytes_per_block)
     return 0;
 }
 
-int drb_hip_alloc (void ** pointer, size_t bytes) { return hipMalloc(pointer, bytes); }
-int drb_hip_free (void * pointer) { return hipFree(pointer); }
-int drb_hip_host_alloc (void ** pointer, size_t bytes) { return hipHostMalloc(pointer, bytes, hipHostMallocDefault); }
-int drb_hip_host_free (void * pointer) { return hipHostFree(pointer); }
+// Every call of the library that allocates or frees through HIP (memory, streams,
+// events) is counted: the entry point that allocates nothing is tested against
+// this count.
+static std::atomic<long long> allocation_calls { 0 };
+
+long long drb_hip_allocation_calls (void) { return allocation_calls.load(); }
+void drb_hip_count_allocation (void) { allocation_calls.fetch_add(1); }
+
+int drb_hip_alloc (void ** pointer, size_t bytes) { allocation_calls.fetch_add(1); return hipMalloc(pointer, bytes); }
+int drb_hip_free (void * pointer) { allocation_calls.fetch_add(1); return hipFree(pointer); }
+int drb_hip_host_alloc (void ** pointer, size_t bytes) { allocation_calls.fetch_add(1); return hipHostMalloc(pointer, bytes, hipHostMallocDefault); }
+int drb_hip_host_free (void * pointer) { allocation_calls.fetch_add(1); return hipHostFree(pointer); }
 
 int drb_hip_memset_async (void * pointer, int value, size_t bytes, void * stream)
 {
@@ -812,6 +868,8 @@ int drb_hip_stream_synchronize (void * stream) { return hipStreamSynchronize(sta
 int drb_hip_stream_create (void ** stream)
 {
     hipStream_t created;
+    allocation_calls.fetch_add(1);
+
     hipError_t const status = hipStreamCreateWithFlags(&created, hipStreamNonBlocking);
     *stream = created;
     return status;
@@ -827,6 +885,8 @@ int drb_hip_stream_wait_event (void * stream, void * event)
 int drb_hip_event_create (void ** event)
 {
     hipEvent_t created;
+    allocation_calls.fetch_add(1);
+
     hipError_t const status = hipEventCreateWithFlags(&created, hipEventDisableTiming);
     *event = created;
     return status;
@@ -835,6 +895,8 @@ int drb_hip_event_create (void ** event)
 int drb_hip_timing_event_create (void ** event)
 {
     hipEvent_t created;
+    allocation_calls.fetch_add(1);
+
     hipError_t const status = hipEventCreate(&created);
     *event = created;
     return status;

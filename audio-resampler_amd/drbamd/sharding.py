@@ -7,6 +7,7 @@ import os
 import socket
 import subprocess
 import sys
+import time
 
 
 def spawn_ranks(world, script, argv, check_devices=True):
@@ -14,7 +15,8 @@ def spawn_ranks(world, script, argv, check_devices=True):
     launcher would set (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR 127.0.0.1, a free
     MASTER_PORT).  The caller must not have touched a GPU yet: the children are
     new processes, nothing is re-executed.  Their output passes through; returns
-    the worst exit code."""
+    0 if every rank ended with 0, else 1 (the other ranks are ended as soon as
+    one fails)."""
     if check_devices:
         import torch
 
@@ -30,7 +32,32 @@ def spawn_ranks(world, script, argv, check_devices=True):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         children.append(subprocess.Popen([sys.executable, os.path.abspath(script)] + list(argv), env=env))
-    return max(child.wait() for child in children)
+    # The ranks meet at barriers: when one dies the others would sit there until
+    # the collective's timeout.  So the children are polled, and as soon as one
+    # ends badly the rest are ended too (the very processes started above, by
+    # their own handles).  A rank killed by a signal counts as 128 + signal.
+    worst = 0
+    running = list(children)
+    while running:
+        for child in list(running):
+            code = child.poll()
+            if code is None:
+                continue
+            running.remove(child)
+            if code != 0:
+                worst = max(worst, 128 - code if code < 0 else code)
+                for other in running:
+                    other.terminate()
+        if running:
+            time.sleep(0.05)
+    for child in children:
+        if child.returncode is None:
+            try:
+                child.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                child.kill()
+                child.wait()
+    return 1 if worst else 0
 
 
 def rank_of_environment():

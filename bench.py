@@ -52,6 +52,11 @@ SIDE_RUNS = [
     ("cfg5", "cfg5_i32_best", {}),                       # int32: the exact kernels, whatever --arithmetic says
     ("headline_4096_frame_calls", "headline", {"call_frames": 4096}),
     ("headline_phases_apart", "headline", {"phases_apart": True}),
+    ("headline_sweep", "headline", {"signal": "sweep"}),
+    ("headline_poor", "headline_poor", {}),
+    ("headline_best", "headline_best", {}),
+    ("headline_exact", "headline", {"arithmetic": "exact"}),
+    ("headline_exact_1s_steps", "headline", {"arithmetic": "exact", "seconds": 1.0}),
 ]
 
 FP32_PEAK_TFLOPS = 157.3    # MI355X float32, vector and matrix instruction alike
@@ -180,8 +185,29 @@ def roofline_of(info, fast, samples_per_launch, kernel_ms, step_ms):
     return out
 
 
+def synthetic_source(torch, signal, streams, ch, frames, rate, limit, device, seed):
+    """[streams, ch, frames] float32 on the device.  noise: uniform white noise in
+    [-1, 1); sweep: a logarithmic sine sweep from 20 Hz to `limit` Hz over the
+    buffer, amplitude 0.5, every stream and channel starting at a phase of its own."""
+    generator = torch.Generator(device=device)
+    generator.manual_seed(seed)
+    if signal == "noise":
+        return torch.rand((streams, ch, frames), device=device, generator=generator) * 2 - 1
+    import math
+    t = torch.arange(frames, device=device, dtype=torch.float64) / rate
+    span = frames / rate
+    k = math.log(limit / 20.0)
+    phase = 2 * math.pi * 20.0 * span / k * (torch.exp(t / span * k) - 1.0)
+    start = torch.rand((streams, ch, 1), device=device, generator=generator, dtype=torch.float64) * 2 * math.pi
+    out = torch.empty((streams, ch, frames), device=device, dtype=torch.float32)
+    for first in range(0, streams, 64):   # (float64 temporaries of a few hundred MB at a time)
+        out[first:first + 64] = (0.5 * torch.sin(phase + start[first:first + 64])).float()
+    return out
+
+
 def measure(name, arithmetic, streams, seconds, steps, warmup, rank, world, local_rank,
-            call_frames=0, ragged=None, phases_apart=False, want_host_fed=False, kernel_probe=6, host_fed_seconds=1.0):
+            call_frames=0, ragged=None, phases_apart=False, want_host_fed=False, kernel_probe=6, host_fed_seconds=1.0,
+            signal="noise"):
     """Runs one workload on this rank's GPU and returns its measurements.  The
     timed region is bracketed by barriers over all ranks and device
     synchronisation on both sides; the time is the slowest rank's."""
@@ -223,9 +249,7 @@ def measure(name, arithmetic, streams, seconds, steps, warmup, rank, world, loca
     source_frames = (other_whole + 8192 if direction == 1 else longest + lead) + int(os.environ.get("BENCH_SOURCE_PAD", "0"))
     target_capacity = longest + lead if direction == 1 else other_whole + 8192 + lead
 
-    generator = torch.Generator(device=device)
-    generator.manual_seed(1234 + rank)
-    noise = torch.rand((streams, ch, source_frames), device=device, generator=generator) * 2 - 1
+    noise = synthetic_source(torch, signal, streams, ch, source_frames, src, 0.45 * min(src, dst), device, 1234 + rank)
     if layout == "interleaved":
         noise = noise.transpose(1, 2).contiguous()
     if sample == "i16":
@@ -378,6 +402,8 @@ def measure(name, arithmetic, streams, seconds, steps, warmup, rank, world, loca
                        arithmetic if fast or arithmetic == "exact" else "exact (int32 samples: fast arithmetic runs the exact kernels)",
                        (", in calls of %d frames" % call_frames if call_frames else "")
                        + (", every stream pushed an odd number of frames of its own beforehand" if phases_apart else "")),
+        "signal": "uniform white noise in [-1, 1)" if signal == "noise"
+                  else "logarithmic sine sweep, 20 Hz to 0.45 x the lower rate, amplitude 0.5, a start phase per stream and channel",
         "name": name, "streams_per_gpu": streams, "frames_per_step": longest, "calls_per_step": calls_per_step,
         "tile_frames": info.fast_tile_frames if fast else info.tile_frames, "history_frames": info.history_frames}
 
@@ -460,7 +486,11 @@ def main():
     if rank == 0:
         src, dst = WORKLOADS[args.workload][:2]
         roofline = main_run["roofline"]
+        # (HBM bytes per launch from the committed rocprofv3 --pmc passes of this command,
+        # profiles/: counters cannot be read from inside the timed process; null where none is kept)
         roofline["traffic"] = traffic_of(args.workload, args.arithmetic, streams, args.seconds)
+        roofline["traffic_source"] = "profiles/traffic.json: TCC_EA0_RDREQ / WRREQ passes of this command, committed with their listing"
+
         line = {
             "metric": "output Msamples/s, %d stereo 44.1->48k streams" % per_gpu if args.workload == "headline"
                       else "output Msamples/s, %s" % args.workload,
@@ -468,7 +498,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": main_run["ms_per_step"], "host_ms_per_step": main_run["host_ms_per_step"],
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": main_run["dtype"], "data": "synthetic white noise, uniform [-1, 1)",
+            "dtype": main_run["dtype"], "data": "synthetic white noise, uniform [-1, 1) (configs[headline_sweep]: the same on a logarithmic sine sweep)",
             "config": dict(main_run["config"], total_streams=total),
             "roofline": roofline,
         }
@@ -478,13 +508,16 @@ def main():
     if single and not args.no_configs and args.workload == "headline" and not args.call_frames and not args.phases_apart:
         configs = []
         for label, name, options in SIDE_RUNS:
+            options = dict(options)
             side_steps = 3 if options.get("call_frames") else 10
+            side_arithmetic = options.pop("arithmetic", args.arithmetic)
+            side_seconds = options.pop("seconds", 10.0)
             try:
-                run = measure(name, args.arithmetic, WORKLOADS[name][9], 10.0, side_steps, 1 if options.get("call_frames") else 4, rank, world, local_rank, **options)
+                run = measure(name, side_arithmetic, WORKLOADS[name][9], side_seconds, side_steps, 1 if options.get("call_frames") else 4, rank, world, local_rank, **options)
             except Exception as error:  # a side measurement never takes the headline down with it
                 configs.append({"name": label, "error": "%s: %s" % (type(error).__name__, error)})
                 continue
-            run["roofline"]["traffic"] = traffic_of(name, args.arithmetic, WORKLOADS[name][9], 10.0)
+            run["roofline"]["traffic"] = traffic_of(label, side_arithmetic, WORKLOADS[name][9], side_seconds)
             configs.append(dict(run, name=label))
         line["configs"] = configs
 

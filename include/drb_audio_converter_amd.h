@@ -281,25 +281,32 @@ extern DrbAmd_Status drb_amd_batch_process_dense
         void * hip_stream
     );
 
-/* drb_amd_batch_process_dense for callers that may not allocate: code under HIP
- * graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has
- * no counterpart upstream (whose converter owns no resources at all).  The
- * same step, with the same results; but the device tables a step needs beyond
- * the batch's per-stream state (step descriptors and, for the collapsed
- * matrix-core kernels, the coefficient tables of the step) live in a static
- * 8 MiB workspace inside the library's code object instead of buffers that
- * grow on demand, and the call makes no hipMalloc / hipFree / hipHostMalloc
- * and no host allocation either.  Limits, reported as drb_amd_error_capacity:
+/* drb_amd_batch_process_dense for callers that may not allocate: tight serving
+ * loops, harnesses that forbid hipMalloc, code that runs while another thread
+ * has a HIP graph capture open on the device.  It has no counterpart upstream
+ * (whose converter owns no resources at all).  The same step, with the same
+ * results; but the device tables a step needs beyond the batch's per-stream
+ * state (step descriptors and, for the collapsed matrix-core kernels, the
+ * coefficient tables of the step) live in a static 8 MiB workspace inside the
+ * library's code object instead of buffers that grow on demand, and the call
+ * makes no hipMalloc / hipFree / hipHostMalloc and no host allocation either.
+ * The call itself is NOT capturable into a HIP graph: phases, delays and frame
+ * counts of the step are worked out on the host and advance with every call (a
+ * replayed graph would run the recorded step's tables again), and the call
+ * waits on an event of the batch's ring of descriptor slots.
+ * Limits, reported as drb_amd_error_capacity:
  * stream_count x launches per step <= 26214 (1 MiB of step descriptors);
  * stream_count x stretches of tiles (32 to 128 tiles each, by rate pair) <= 131072; a chain of several launches
  * must have run a step at least this long through drb_amd_batch_process before
  * (its buffers between launches do not grow here).  Where the streams' phases
  * differ so much that their coefficient sets exceed the workspace (about 47
- * sets), the step runs the kernels that need none.  Every batch on a GPU
- * shares that GPU's workspace: calls on DIFFERENT batches of one GPU must not
- * overlap in time (calls on one batch are ordered by the library, as for
- * drb_amd_batch_process); it keeps the last call's contents and is rewritten
- * by every call before anything reads it. */
+ * sets), the step runs in groups of streams whose sets fit, one after the other.
+ * Every batch on a GPU shares that GPU's workspace: a call on another HIP stream
+ * than the last static call's (of whichever batch) waits for that call's work
+ * first; calls from DIFFERENT threads on batches of one GPU must not overlap in
+ * time (calls on one batch never may, as for drb_amd_batch_process).  The
+ * workspace keeps the last call's contents and is rewritten by every call
+ * before anything reads it. */
 extern DrbAmd_Status drb_amd_batch_process_dense_static
     (
         DrbAmd_Batch * batch,
@@ -340,6 +347,17 @@ extern DrbAmd_Status drb_amd_batch_kernel_ms (DrbAmd_Batch * batch, float * mill
 /* The same for everything the most recent step ran on the device: descriptor
  * upload, coefficient sets, filter kernels, history update. */
 extern DrbAmd_Status drb_amd_batch_step_ms (DrbAmd_Batch * batch, float * milliseconds);
+
+/* How often this library has allocated or freed anything so far, on the host or
+ * through HIP (device and pinned memory, streams, events): what a caller that
+ * may not allocate checks drb_amd_batch_process_dense_static against. */
+extern long long drb_amd_allocation_calls (void);
+
+/* In how many groups of streams the most recent step ran its collapsed
+ * matrix-core launch: 1, unless the distinct phases of the step's streams
+ * needed more coefficient sets than their memory holds at a time (1 GiB, or
+ * the static workspace), in which case the groups ran one after the other. */
+extern int drb_amd_batch_step_groups (DrbAmd_Batch const * batch);
 
 /* Planner facts for a configuration (host only, no device needed): the DSP
  * stages in data-flow order and the sizes the kernels derive from them. */

@@ -339,3 +339,49 @@ def test_fast_mode_reports_samples_its_halves_cannot_carry(bad):
                 tail = slice(frames * 48000 // 44100 + 2048, made)
                 assert_close(got[s, :, tail], want[:, tail], "stream 1 behind the bad sample")
         batch.close()
+
+
+@pytest.mark.parametrize("entry", ["regular", "static"])
+def test_more_phases_than_coefficient_sets_fit_runs_in_groups_of_streams(entry, monkeypatch):
+    """16 -> 48 kHz has its two interpolators folded into the one filter and no
+    staged kernels to fall back to.  64 streams, every one at a phase of its
+    own, with room for about twenty coefficient sets at a time (the limit
+    lowered through the environment; the static workspace holds about seventy
+    of this chain's sets as it is): the step is not refused, it runs in groups
+    of streams, every stream against an upstream converter of its own."""
+    src, dst, ch, n = 16000, 48000, 1, 64
+    if entry == "regular":
+        monkeypatch.setenv("DRB_AMD_SET_BYTES_LIMIT", "1800000")
+    status, plan = support.oracle_plan(src, dst, ch, 256, 16, PUSH, support.GOOD)
+    assert status == 1
+    config = drbamd.make_config(src, dst, ch, 256, 16, PUSH, support.GOOD, arithmetic=drbamd.FAST, streams=n)
+    info = drbamd.plan_info(config)
+    assert info.fast_path == 1 and info.fast_launches == 1 and info.fast_collapsed == 2
+    first = [1001 + 37 * s for s in range(n)]     # every stream its own length: phases apart from here on
+    long = 3 * src
+    inputs = [support.white_noise(ch, first[s] + long, 700 + s) for s in range(n)]
+    runner = gpu_support.StreamRunner(config, inputs)
+    runner.step(first)
+    if entry == "regular":
+        runner.step([long] * n)
+        assert runner.batch.step_groups() > 3
+        got = [runner.result(s) for s in range(n)]
+    else:
+        before = [runner.result(s) for s in range(n)]
+        rest = np.stack([inputs[s][:, first[s]:] for s in range(n)])
+        source = torch.from_numpy(rest).cuda()
+        capacity = 3 * long + 4096
+        target = torch.zeros((n, ch, capacity), device="cuda:0")
+        counts = (ctypes.c_int * n)()
+        stream = torch.cuda.current_stream().cuda_stream
+        runner.batch.process_dense_static(source.data_ptr(), ch * long, long, target.data_ptr(), ch * capacity, capacity,
+                                          long, capacity, stream=stream, produced=counts)
+        runner.batch.synchronize(stream)
+        assert runner.batch.step_groups() > 1
+        out = target.cpu().numpy()
+        got = [np.concatenate([before[s], out[s, :, :counts[s]]], axis=1) for s in range(n)]
+    for s in range(n):
+        want = support.oracle_push(plan, inputs[s])
+        assert got[s].shape == want.shape, s
+        assert_close(got[s], want, "stream %d" % s)
+    runner.close()

@@ -110,3 +110,23 @@ def test_bench_starts_its_own_ranks_only_outside_a_launcher():
                           env=env, capture_output=True, text=True, timeout=120)
     assert done.returncode == 2
     assert "2 GPUs asked for, 0 visible" in done.stderr
+
+
+def test_launcher_reports_a_rank_that_dies_and_ends_the_others(tmp_path):
+    """A rank killed by a signal (a GPU abort is -6 to its parent) must not read as
+    success, and the ranks that wait for it at a barrier must not wait on."""
+    import time
+
+    sys.path.insert(0, os.path.join(support.ROOT, "audio-resampler_amd"))
+    from drbamd import sharding
+
+    worker = tmp_path / "dies.py"
+    worker.write_text(
+        "import os, signal, time\n"
+        "if os.environ['RANK'] == '1':\n"
+        "    os.kill(os.getpid(), signal.SIGABRT)\n"
+        "time.sleep(120)\n")
+    started = time.time()
+    code = sharding.spawn_ranks(2, str(worker), [], check_devices=False)
+    assert code == 1
+    assert time.time() - started < 60

@@ -4,7 +4,10 @@ configuration, fed the same chunks, one through each entry point; two calls in
 a row, the second with a smaller input.  Both run the same kernels on the same
 data, so the outputs are compared bit for bit (which meets the parity bar of
 either arithmetic mode: the regular entry point's outputs are checked against
-the upstream converter by the other tests)."""
+the upstream converter by the other tests).  Around every static call the
+free device memory (hipMemGetInfo) and the library's own count of its
+allocation calls (host, device, pinned, streams, events) are read: both must
+be what they were."""
 import ctypes
 
 import numpy as np
@@ -43,9 +46,19 @@ def test_static_entry_point_matches_the_regular_one(case):
     for frames in calls:
         for which, (batch, entry) in enumerate(((regular, regular.process_dense), (static, static.process_dense_static))):
             counts = (ctypes.c_int * streams)()
+            if which == 1:
+                # the property itself: device memory as it was, no allocation call of the library's
+                torch.cuda.synchronize()
+                free_before = torch.cuda.mem_get_info()[0]
+                calls_before = drbamd.lib.drb_amd_allocation_calls()
             entry(source.data_ptr() + 4 * at, ch * total, total,
                   outputs[which].data_ptr() + 4 * made[which], ch * capacity, capacity,
                   frames, capacity - made[which], stream=stream, produced=counts)
+            if which == 1:
+                calls_after = drbamd.lib.drb_amd_allocation_calls()
+                torch.cuda.synchronize()
+                assert torch.cuda.mem_get_info()[0] == free_before, "device memory allocated by the static entry point"
+                assert calls_after == calls_before, "the static entry point allocated or freed something"
             assert len(set(counts)) == 1
             made[which] += counts[0]
         at += frames
