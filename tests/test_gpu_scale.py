@@ -153,3 +153,44 @@ def test_long_streams_of_every_benchmark_configuration(case):
     runner.close()
     if sample != "i16":
         print("%s: worst excess over the bound %.3g" % (name, worst))
+
+
+CORRELATED = [
+    # the rate pairs whose fast arithmetic has the least margin on noise
+    ("cfg5 as float32", 192000, 44100, support.BEST, "interleaved"),
+    ("176.4 -> 192 kHz", 176400, 192000, support.GOOD, "planar"),
+    ("192 -> 176.4 kHz", 192000, 176400, support.GOOD, "planar"),
+]
+
+
+@pytest.mark.parametrize("case", CORRELATED, ids=[c[0] for c in CORRELATED])
+def test_long_correlated_signals_where_the_margin_is_thinnest(case):
+    """Ten seconds of a full-scale 997 Hz sine and of a constant 1.0: signals whose
+    rounding errors do not average out from tap to tap the way noise's do (every
+    window sees nearly the same samples, so what the split products drop adds
+    up with one sign).  Two streams, one in a single call and one in calls of
+    uneven length, against the upstream converter's restatement."""
+    import gpu_support
+
+    name, src, dst, quality, layout = case
+    ch, frames = 2, 10 * src
+    layout_type = drbamd.INTERLEAVED if layout == "interleaved" else drbamd.PLANAR
+    config = drbamd.make_config(src, dst, ch, 256, 16, PUSH, quality, layout=layout_type, arithmetic=drbamd.FAST, streams=2)
+    assert drbamd.plan_info(config).fast_path == 1
+    status, plan = support.oracle_plan(src, dst, ch, 256, 16, PUSH, quality)
+    assert status == 1
+    t = np.arange(frames, dtype=np.float64) / src
+    sine = np.sin(2 * np.pi * 997.0 * t).astype(np.float32)
+    inputs = [np.stack([sine, -sine]), np.ones((ch, frames), np.float32)]
+    runner = gpu_support.StreamRunner(config, inputs)
+    schedules = [gpu_support.chunk_schedule(frames, p) for p in ([10 ** 9], [4096 * 7, 256, 4096 * 50])]
+    for i in range(max(len(s) for s in schedules)):
+        runner.step([s[i] if i < len(s) else 0 for s in schedules])
+    for s, what in enumerate(("sine", "constant")):
+        got = runner.result(s)
+        want = support.oracle_push(plan, inputs[s])
+        assert got.shape == want.shape, (name, what)
+        excess, at, err = excess_of(got, want)
+        print("%s, %s: worst excess over the bound %.3g, worst |error| %.3g" % (name, what, excess, err))
+        assert excess <= 0, "%s, %s: |err| %.3g at %d" % (name, what, err, at)
+    runner.close()
