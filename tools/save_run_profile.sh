@@ -5,7 +5,7 @@ set -e
 TAG=$1; NAME=$2
 python3 tools/save_profile.py gpurun_out/$TAG/trace profiles/$NAME
 cp gpurun_out/$TAG/dispatches.txt profiles/${NAME}_dispatches.txt
-cp gpurun_out/$TAG/bench.json profiles/r02_bench_default_with_configs.json
+cp gpurun_out/$TAG/bench.json profiles/${NAME%%_*}_bench_default_with_configs.json
 python3 - gpurun_out/$TAG/pmc_summary.txt profiles/${NAME}_pmc.txt <<'PY'
 import re, sys
 text = open(sys.argv[1]).read()
