@@ -120,6 +120,7 @@ struct DrbAmd_Batch
     size_t collapse_hash_room;
     Collapse_Group groups [max_groups];        /* of the step at hand          */
     int group_count;
+    int step_walkers;       /* the most recent collapsed launch: workgroups that went from stream to stream (0: none) */
     size_t set_bytes_limit;                    /* collapse_set_bytes_limit, or DRB_AMD_SET_BYTES_LIMIT (diagnostic) */
     int wish_apart;                            /* DRB_AMD_FAST_APART (diagnostic): 1 always the staged kernels, 0 never, -1 unset */
 
@@ -720,12 +721,14 @@ DrbAmd_Status drb_amd_batch_create (DrbAmd_Batch_Config const * config, DrbAmd_B
 
     char const * const stride = getenv("DRB_AMD_FAST_TILE_STRIDE");
     char const * const no_carry = getenv("DRB_AMD_FAST_NO_CARRY");
+    char const * const unit_walk = getenv("DRB_AMD_UNIT_WALK");
 
     for (int i = 0; i < batch->launch_count; i++)
     {
         batch->launches[i].fast.ablate = ablate ? atoi(ablate) : 0;
         batch->launches[i].fast.tile_stride = stride ? atoi(stride) : 0;
         batch->launches[i].fast.no_carry = no_carry ? atoi(no_carry) : 0;
+        batch->launches[i].fast.unit_walk = unit_walk ? atoi(unit_walk) : 0;
         batch->launches[i].fast.rebuild_tiles = getenv("DRB_AMD_FAST_REBUILD_TILES") ? atoi(getenv("DRB_AMD_FAST_REBUILD_TILES")) : 0;
 
         /* How many tiles one coefficient set of the split kernel serves follows from how
@@ -1200,7 +1203,9 @@ DrbAmd_Status drb_amd_batch_process
 
     /* frames between the launches: an interpolator on its own doubles what it
      * gets; everything from the sinc stage on is counted back from the target */
-    for (int l = 0; l < launches; l++) most[l] = 0;
+    long long least [max_launches];  /* and fewest */
+
+    for (int l = 0; l < launches; l++) { most[l] = 0; least[l] = 0x7fffffffffffffffLL; }
 
     for (int s = 0; s < n; s++)
     {
@@ -1215,6 +1220,7 @@ DrbAmd_Status drb_amd_batch_process
                    : (long long)batch->steps[s].target_frames << launch->downs_behind;
 
             if (frames > most[l]) most[l] = frames;
+            if (frames < least[l]) least[l] = frames;
         }
     }
 
@@ -1280,6 +1286,7 @@ DrbAmd_Status drb_amd_batch_process
     int collapse_stretches = 1, collapse_job_count = 0;
 
     batch->pending_bytes[0] = batch->pending_bytes[1] = 0;   /* (set by collapse_prepare where a step needs them) */
+    batch->step_walkers = 0;
     int apart [max_launches];   /* 1: this step runs the launch's three stages apart */
 
     HOST_MARK(1);
@@ -1378,11 +1385,12 @@ DrbAmd_Status drb_amd_batch_process
 
                     if (!code) code = drb_hip_launch_collapsed
                     (
-                        shape, launch_calls + group->first_stream, group->stream_count, (int)((most[l] + fast_tile - 1) / fast_tile),
+                        shape, launch_calls + group->first_stream, group->stream_count,
+                        (int)((most[l] + fast_tile - 1) / fast_tile), (int)((least[l] + fast_tile - 1) / fast_tile),
                         past, source_stride, target_stride,
                         batch->collapse_jobs + group->first_job,
                         batch->collapse_spots + (size_t)group->first_stream * collapse_stretches, collapse_stretches,
-                        batch->collapse_sets, batch->fault_device, hip_stream
+                        batch->collapse_sets, batch->fault_device, hip_stream, &batch->step_walkers
                     );
                 }
             }
@@ -1803,6 +1811,11 @@ long long drb_amd_allocation_calls (void)
 int drb_amd_batch_step_groups (DrbAmd_Batch const * batch)
 {
     return batch ? batch->group_count : 0;
+}
+
+int drb_amd_batch_step_walkers (DrbAmd_Batch const * batch)
+{
+    return batch ? batch->step_walkers : 0;
 }
 
 #ifdef DRB_FAST_STAMPS

@@ -65,6 +65,8 @@ typedef struct Drb_Fast_Chain
     int usable;
     int ablate;                             /* diagnostic: bit mask of phases to skip (timing only) */
     int tile_stride;                        /* diagnostic: tiles between a workgroup's tiles (0: chosen by the launcher) */
+    int unit_walk;                          /* split kernel: workgroups that go from stream to stream where every stream has as many tiles
+                                               (0: chosen by the launcher, -1: never, else: so many) */
     int rebuild_tiles;                      /* tiles of a stream between exact rebuilds of the sinc coefficients (0: the kernel's default) */
     int no_carry;                           /* diagnostic: every tile warms up on its own segment 0 */
     int channels, sample_type, layout, history;   /* sample_type, layout: of the source */
@@ -229,12 +231,12 @@ int drb_hip_launch_collapse_build
 int drb_hip_launch_collapsed
     (
         Drb_Fast_Chain const * chain,
-        Drb_Device_Call const * calls, int stream_count, int max_tiles,
+        Drb_Device_Call const * calls, int stream_count, int max_tiles, int min_tiles,
         float const * history,
         long long source_channel_stride, long long target_channel_stride,
         Drb_Collapse_Job const * jobs, Drb_Collapse_Spot const * spots, int max_stretches,
         unsigned int const * sets,
-        int * fault_flag, void * stream
+        int * fault_flag, void * stream, int * walkers_out   /* (may be null) how many workgroups went from stream to stream, 0: none */
     );
 
 /* Writes every stream's new look-back (the last `history` source frames seen

@@ -2026,31 +2026,26 @@ extern "C" int drb_hip_launch_collapse_build
 extern "C" int drb_hip_launch_collapsed
     (
         Drb_Fast_Chain const * chain,
-        Drb_Device_Call const * calls, int stream_count, int max_tiles,
+        Drb_Device_Call const * calls, int stream_count, int max_tiles, int min_tiles,
         float const * history,
         long long source_channel_stride, long long target_channel_stride,
         Drb_Collapse_Job const * jobs, Drb_Collapse_Spot const * spots, int max_stretches,
         unsigned int const * sets,
-        int * fault_flag, void * stream
+        int * fault_flag, void * stream, int * walkers_out
     )
 {
+    if (walkers_out) *walkers_out = 0;
+
     if (stream_count <= 0 || max_tiles <= 0) return 0;
 
     if (chain->kind != 4) return hipErrorInvalidValue;
 
-    Split_Kernel * const split = pick_split(chain);
+    Split_Kernel * split = pick_split(chain);
 
     if (!split || max_stretches < 1) return hipErrorInvalidValue;
 
     size_t const bytes = static_cast<size_t>(chain->lds_floats) * sizeof(unsigned);
-
-    if (bytes > 48 * 1024)
-    {
-        hipError_t const status = hipFuncSetAttribute(reinterpret_cast<void const *>(split),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
-
-        if (status != hipSuccess) return status;
-    }
+    unsigned const threads = static_cast<unsigned>(64 * (chain->blocks + kSplitLoaders));
 
     // one workgroup fills a CU; a workgroup walks over the tiles of its stream
     // and channel (or channel pair) with a stride, a few workgroups per CU in all
@@ -2062,11 +2057,63 @@ extern "C" int drb_hip_launch_collapsed
     if (stride < 1) stride = 1;
     if (pairs * stride > 0x7fffffffLL) return hipErrorInvalidValue;
 
-    split<<<dim3(static_cast<unsigned>(pairs * stride)), dim3(static_cast<unsigned>(64 * (chain->blocks + kSplitLoaders))), bytes, static_cast<hipStream_t>(stream)>>>
-    (
-        *chain, calls, stream_count, static_cast<int>(stride), history,
-        source_channel_stride, target_channel_stride, jobs, spots, max_stretches, sets, fault_flag
-    );
+    // Many streams of a few tiles each, all of as many tiles: as many workgroups as
+    // the chip holds at a time, each of which goes from stream to stream (a
+    // workgroup's set-up and the latency of its first loads then come once per
+    // workgroup, not once per tile or two).
+    long long walkers = 0;
+    Split_Kernel * const walking = min_tiles == max_tiles && chain->unit_walk >= 0 ? pick_split(chain, true) : nullptr;
+
+    if (walking)
+    {
+        int per_cu = 0, device = 0, cus = 0;
+
+        if (bytes > 48 * 1024)
+        {
+            hipError_t const status = hipFuncSetAttribute(reinterpret_cast<void const *>(walking),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+
+            if (status != hipSuccess) return status;
+        }
+
+        if (chain->unit_walk > 0) walkers = chain->unit_walk;
+        else if (max_tiles <= kSplitWalkTiles
+                 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<void const *>(walking), static_cast<int>(threads), bytes) == hipSuccess
+                 && hipGetDevice(&device) == hipSuccess
+                 && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess)
+        {
+            walkers = static_cast<long long>(per_cu) * cus;
+        }
+
+        if (walkers >= pairs) walkers = 0;   // (a workgroup per unit: nothing to walk)
+    }
+
+    if (walkers <= 0 && bytes > 48 * 1024)
+    {
+        hipError_t const status = hipFuncSetAttribute(reinterpret_cast<void const *>(split),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+
+        if (status != hipSuccess) return status;
+    }
+
+    if (walkers_out) *walkers_out = static_cast<int>(walkers);
+
+    if (walkers > 0)
+    {
+        walking<<<dim3(static_cast<unsigned>(walkers)), dim3(threads), bytes, static_cast<hipStream_t>(stream)>>>
+        (
+            *chain, calls, stream_count, 1, static_cast<int>(walkers), history,
+            source_channel_stride, target_channel_stride, jobs, spots, max_stretches, sets, fault_flag
+        );
+    }
+    else
+    {
+        split<<<dim3(static_cast<unsigned>(pairs * stride)), dim3(threads), bytes, static_cast<hipStream_t>(stream)>>>
+        (
+            *chain, calls, stream_count, static_cast<int>(stride), static_cast<int>(pairs), history,
+            source_channel_stride, target_channel_stride, jobs, spots, max_stretches, sets, fault_flag
+        );
+    }
 
     return hipGetLastError();
 }

@@ -85,6 +85,7 @@ lib.drb_amd_batch_time_kernels.argtypes = [ctypes.c_void_p, ctypes.c_int]
 lib.drb_amd_batch_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
 lib.drb_amd_batch_step_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
 lib.drb_amd_batch_step_groups.argtypes = [ctypes.c_void_p]
+lib.drb_amd_batch_step_walkers.argtypes = [ctypes.c_void_p]
 lib.drb_amd_allocation_calls.restype = ctypes.c_longlong
 lib.drb_amd_plan_info.argtypes = [ctypes.POINTER(BatchConfig), ctypes.POINTER(PlanInfo)]
 lib.drb_audio_converter_alignment_and_size.restype = ctypes.c_bool
@@ -237,6 +238,9 @@ class Batch:
 
     def step_groups(self):
         return lib.drb_amd_batch_step_groups(self.handle)
+
+    def step_walkers(self):
+        return lib.drb_amd_batch_step_walkers(self.handle)
 
     def synchronize(self, stream=None):
         check(lib.drb_amd_batch_synchronize(self.handle, ctypes.c_void_p(stream or 0)))

@@ -359,6 +359,12 @@ extern long long drb_amd_allocation_calls (void);
  * the static workspace), in which case the groups ran one after the other. */
 extern int drb_amd_batch_step_groups (DrbAmd_Batch const * batch);
 
+/* How many workgroups of the most recent step's collapsed launch went on from
+ * stream to stream (0: every stream and channel had workgroups of its own,
+ * or the step ran other kernels).  Steps of a few thousand frames for each of
+ * many streams run that way, where every stream gets as many tiles. */
+extern int drb_amd_batch_step_walkers (DrbAmd_Batch const * batch);
+
 /* Planner facts for a configuration (host only, no device needed): the DSP
  * stages in data-flow order and the sizes the kernels derive from them. */
 typedef struct DrbAmd_Plan_Info

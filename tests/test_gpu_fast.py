@@ -346,10 +346,10 @@ def test_more_phases_than_coefficient_sets_fit_runs_in_groups_of_streams(entry, 
     """16 -> 48 kHz has its two interpolators folded into the one filter and no
     staged kernels to fall back to.  64 streams, every one at a phase of its
     own, with room for about twenty coefficient sets at a time (the limit
-    lowered through the environment; the static workspace holds about seventy
-    of this chain's sets as it is): the step is not refused, it runs in groups
-    of streams, every stream against an upstream converter of its own."""
-    src, dst, ch, n = 16000, 48000, 1, 64
+    lowered through the environment), or 96 streams in the static workspace,
+    which holds 65 of this chain's sets: the step is not refused, it runs in
+    groups of streams, every stream against an upstream converter of its own."""
+    src, dst, ch, n = 16000, 48000, 1, 64 if entry == "regular" else 96
     if entry == "regular":
         monkeypatch.setenv("DRB_AMD_SET_BYTES_LIMIT", "1800000")
     status, plan = support.oracle_plan(src, dst, ch, 256, 16, PUSH, support.GOOD)
@@ -384,4 +384,68 @@ def test_more_phases_than_coefficient_sets_fit_runs_in_groups_of_streams(entry, 
         want = support.oracle_push(plan, inputs[s])
         assert got[s].shape == want.shape, s
         assert_close(got[s], want, "stream %d" % s)
+    runner.close()
+
+
+WALKED = [
+    # name, src, dst, quality, sample, layout, streams, workgroups
+    ("headline planar float32", 44100, 48000, support.GOOD, "f32", "planar", 7, 3),
+    ("int16 interleaved", 48000, 44100, support.FINE, "i16", "interleaved", 7, 3),
+    ("int16 planar", 48000, 44100, support.GOOD, "i16", "planar", 5, 4),
+    ("headline at best quality", 44100, 48000, support.BEST, "f32", "planar", 9, 2),
+    ("float32 interleaved", 44100, 48000, support.FINE, "f32", "interleaved", 9, 2),
+    ("fewer phases than a launch's sets", 88200, 96000, support.GOOD, "f32", "planar", 6, 5),
+]
+
+
+@pytest.mark.parametrize("case", WALKED, ids=[c[0] for c in WALKED])
+def test_workgroups_that_go_from_stream_to_stream(case, monkeypatch):
+    """Steps in which every stream has as many tiles run with fewer workgroups than
+    streams and channels: each goes on from one stream to the next (here forced
+    to 2 .. 5 workgroups, unevenly loaded; coefficient sets renewed every 2
+    tiles, so that a workgroup's tiles of one stream fall into several
+    stretches).  The streams are at phases of their own after a first step of
+    uneven lengths; then come steps of 4096 frames, one of 3 frames, one long
+    one, and one in which one stream gets more tiles than the others (which
+    must run the ordinary way)."""
+    name, src, dst, quality, sample, layout, n, workgroups = case
+    ch = 2
+    monkeypatch.setenv("DRB_AMD_UNIT_WALK", str(workgroups))
+    monkeypatch.setenv("DRB_AMD_FAST_APART", "0")
+    monkeypatch.setenv("DRB_AMD_FAST_REBUILD_TILES", "2")
+    sample_type = {"f32": drbamd.F32, "i16": drbamd.I16}[sample]
+    layout_type = drbamd.INTERLEAVED if layout == "interleaved" else drbamd.PLANAR
+    config = drbamd.make_config(src, dst, ch, 256, 16, PUSH, quality, sample_type=sample_type, layout=layout_type,
+                                arithmetic=drbamd.FAST, streams=n)
+    info = drbamd.plan_info(config)
+    assert info.fast_collapsed == 2
+    status, plan = support.oracle_plan(src, dst, ch, 256, 16, PUSH, quality)
+    assert status == 1
+    first = [2 * (300 + 700 * s) + (s % 3 == 0) for s in range(n)]
+    steps = [first, [4096] * n, [4096] * n, [3] * n, [4096] * n, [30000] * n, [4096 + (20000 if s == 2 else 0) for s in range(n)], [4096] * n]
+    total = [sum(step[s] for step in steps) for s in range(n)]
+    noise = [support.white_noise(ch, total[s], 900 + s) for s in range(n)]
+    if sample == "i16":
+        inputs = [np.round(x * 32767).astype(np.int16) for x in noise]
+        floats = [support.oracle_convert_samples(x, "f32") for x in inputs]
+    else:
+        inputs, floats = noise, noise
+    runner = gpu_support.StreamRunner(config, inputs)
+    walked = 0
+    for step in steps:
+        produced = runner.step(step)
+        tiles = set(-(-count // info.fast_tile_frames) for count in produced)
+        expect = workgroups if len(tiles) == 1 and max(tiles) > 0 else 0
+        assert runner.batch.step_walkers() == expect, (step[:3], runner.batch.step_walkers(), produced)
+        walked += expect > 0
+    assert walked >= 5
+    for s in range(n):
+        got = runner.result(s)
+        want = support.oracle_push(plan, floats[s])
+        assert got.shape == want.shape, (name, s, got.shape, want.shape)
+        if sample == "i16":
+            want_q = support.oracle_convert_samples(np.ascontiguousarray(want), "i16")
+            assert np.abs(got.astype(np.int64) - want_q.astype(np.int64)).max() <= 1, (name, s)
+        else:
+            assert_close(got, want, "%s stream %d" % (name, s))
     runner.close()
