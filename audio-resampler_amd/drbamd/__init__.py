@@ -84,9 +84,13 @@ lib.drb_amd_batch_synchronize.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 lib.drb_amd_batch_time_kernels.argtypes = [ctypes.c_void_p, ctypes.c_int]
 lib.drb_amd_batch_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
 lib.drb_amd_batch_step_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
-lib.drb_amd_batch_step_groups.argtypes = [ctypes.c_void_p]
-lib.drb_amd_batch_step_walkers.argtypes = [ctypes.c_void_p]
-lib.drb_amd_allocation_calls.restype = ctypes.c_longlong
+# (diagnostics that a build of the library named by DRB_AMD_LIB for comparison may lack)
+if hasattr(lib, "drb_amd_batch_step_groups"):
+    lib.drb_amd_batch_step_groups.argtypes = [ctypes.c_void_p]
+if hasattr(lib, "drb_amd_batch_step_walkers"):
+    lib.drb_amd_batch_step_walkers.argtypes = [ctypes.c_void_p]
+if hasattr(lib, "drb_amd_allocation_calls"):
+    lib.drb_amd_allocation_calls.restype = ctypes.c_longlong
 lib.drb_amd_plan_info.argtypes = [ctypes.POINTER(BatchConfig), ctypes.POINTER(PlanInfo)]
 lib.drb_audio_converter_alignment_and_size.restype = ctypes.c_bool
 lib.drb_audio_converter_alignment_and_size.argtypes = [ctypes.c_int] * 7 + [

@@ -391,6 +391,7 @@ WALKED = [
     # name, src, dst, quality, sample, layout, streams, workgroups
     ("headline planar float32", 44100, 48000, support.GOOD, "f32", "planar", 7, 3),
     ("int16 interleaved", 48000, 44100, support.FINE, "i16", "interleaved", 7, 3),
+    ("cfg2 int16 interleaved", 48000, 44100, support.GOOD, "i16", "interleaved", 7, 3),
     ("int16 planar", 48000, 44100, support.GOOD, "i16", "planar", 5, 4),
     ("headline at best quality", 44100, 48000, support.BEST, "f32", "planar", 9, 2),
     ("float32 interleaved", 44100, 48000, support.FINE, "f32", "interleaved", 9, 2),

@@ -10,3 +10,6 @@ import json,sys
 d=json.load(open(sys.argv[1])); r=d["roofline"]; print(sys.argv[2], "value", d["value"], "ms/step", d["ms_per_step"], "host", d["host_ms_per_step"], "kernel_ms", r["kernel_ms"], r["frac"], r["kernel"])' gpurun_out/u01/short_$apart.json $apart
 grep "host us" gpurun_out/u01/short_$apart.err
 done
+if [ -n "$STAMPS" ]; then
+DRB_AMD_FAST_APART=0 STAMP_FRAMES=4096 STAMP_WORKGROUPS=256 DRB_AMD_LIB=audio-resampler_amd/lib/libdrb_audio_converter_amd_stamps.so timeout -k 10 200 python3 tools/stamp_split.py || exit 1
+fi

@@ -56,7 +56,9 @@ def main():
           + "  ".join("%s %.0f" % (LOADER[p], row[p] / tiles) for p in range(4))
           + ("  (it converts a third of every second tile)" if cfg2 else "  (it converts half of every third tile)"))
     if counters[9]:
-        life, real = counters[8] / (streams * groups), counters[9] / (streams * groups)
+        # (steps of a few tiles per stream run with as many workgroups as the chip holds: say how many)
+        workgroups = int(os.environ.get("STAMP_WORKGROUPS", str(streams * groups)))
+        life, real = counters[8] / workgroups, counters[9] / workgroups
         print("workgroup lifetime %.0f cycles = %.2f us: shader clock %.2f GHz" % (life, real / 100.0, life / real * 0.1))
 
 
