@@ -2062,7 +2062,9 @@ extern "C" int drb_hip_launch_collapsed
     // workgroup's set-up and the latency of its first loads then come once per
     // workgroup, not once per tile or two).
     long long walkers = 0;
-    Split_Kernel * const walking = min_tiles == max_tiles && chain->unit_walk >= 0 ? pick_split(chain, true) : nullptr;
+    // (a step of long streams does not so much as look the other kernel up)
+    bool const may_walk = min_tiles == max_tiles && (chain->unit_walk > 0 || (chain->unit_walk == 0 && max_tiles <= kSplitWalkTiles));
+    Split_Kernel * const walking = may_walk ? pick_split(chain, true) : nullptr;
 
     if (walking)
     {
