@@ -228,6 +228,8 @@ int drb_hip_launch_collapse_build
         Drb_Fast_Chain const * chain, Drb_Collapse_Job const * jobs, int job_count,
         unsigned int * sets, int * fault_flag, void * stream
     );
+/* how many workgroups of such a launch would go from stream to stream (0: none) */
+int drb_hip_collapsed_walkers (Drb_Fast_Chain const * chain, int stream_count, int max_tiles, int min_tiles);
 int drb_hip_launch_collapsed
     (
         Drb_Fast_Chain const * chain,

@@ -34,6 +34,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "drb_hip.h"
 
 namespace
@@ -2023,6 +2025,65 @@ extern "C" int drb_hip_launch_collapse_build
     return hipGetLastError();
 }
 
+// Many streams of a few tiles each, all of as many tiles: as many workgroups as the
+// chip holds at a time, each of which goes from stream to stream (a workgroup's
+// set-up and the latency of its first loads then come once per workgroup, not
+// once per tile or two).  How many such workgroups a launch gets (0: every
+// stream and channel gets workgroups of its own; below 0: a HIP call failed),
+// and their kernel.
+static long long split_walkers (Drb_Fast_Chain const * chain, int stream_count, int max_tiles, int min_tiles, Split_Kernel ** kernel_out)
+{
+    // (a step of long streams does not so much as look the other kernel up)
+    bool const may_walk = min_tiles == max_tiles && (chain->unit_walk > 0 || (chain->unit_walk == 0 && max_tiles <= kSplitWalkTiles));
+    Split_Kernel * const walking = may_walk ? pick_split(chain, true) : nullptr;
+
+    if (kernel_out) *kernel_out = walking;
+    if (!walking) return 0;
+
+    size_t const bytes = static_cast<size_t>(chain->lds_floats) * sizeof(unsigned);
+    int const threads = 64 * (chain->blocks + kSplitLoaders);
+    long long const pairs = static_cast<long long>(stream_count) * (chain->layout == kInterleaved && chain->channels == 2 ? 1 : chain->channels);
+    long long walkers = chain->unit_walk > 0 ? chain->unit_walk : 0;
+
+    if (walkers == 0)
+    {
+        // how many of the kernel's workgroups the chip holds: asked once per kernel and size
+        struct Held { Split_Kernel * kernel; size_t bytes; int device; long long workgroups; };
+        static Held held [8] = {};
+        static int next = 0;
+        static std::mutex held_lock;
+        std::lock_guard<std::mutex> const guard(held_lock);
+        int device = 0;
+
+        if (hipGetDevice(&device) != hipSuccess) return -1;
+
+        for (Held const & one : held) if (one.kernel == walking && one.bytes == bytes && one.device == device) walkers = one.workgroups;
+
+        if (walkers == 0)
+        {
+            int per_cu = 0, cus = 0;
+
+            if (bytes > 48 * 1024
+                && hipFuncSetAttribute(reinterpret_cast<void const *>(walking), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)) != hipSuccess) return -1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<void const *>(walking), threads, bytes) != hipSuccess) return -1;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return -1;
+
+            walkers = static_cast<long long>(per_cu) * cus;
+            held[next] = Held{ walking, bytes, device, walkers };
+            next = (next + 1) % 8;
+        }
+    }
+
+    return walkers >= pairs ? 0 : walkers;   // (a workgroup per unit: nothing to walk)
+}
+
+extern "C" int drb_hip_collapsed_walkers (Drb_Fast_Chain const * chain, int stream_count, int max_tiles, int min_tiles)
+{
+    long long const walkers = chain->kind == 4 && pick_split(chain) ? split_walkers(chain, stream_count, max_tiles, min_tiles, nullptr) : 0;
+
+    return walkers > 0 ? static_cast<int>(walkers) : 0;
+}
+
 extern "C" int drb_hip_launch_collapsed
     (
         Drb_Fast_Chain const * chain,
@@ -2057,42 +2118,14 @@ extern "C" int drb_hip_launch_collapsed
     if (stride < 1) stride = 1;
     if (pairs * stride > 0x7fffffffLL) return hipErrorInvalidValue;
 
-    // Many streams of a few tiles each, all of as many tiles: as many workgroups as
-    // the chip holds at a time, each of which goes from stream to stream (a
-    // workgroup's set-up and the latency of its first loads then come once per
-    // workgroup, not once per tile or two).
-    long long walkers = 0;
-    // (a step of long streams does not so much as look the other kernel up)
-    bool const may_walk = min_tiles == max_tiles && (chain->unit_walk > 0 || (chain->unit_walk == 0 && max_tiles <= kSplitWalkTiles));
-    Split_Kernel * const walking = may_walk ? pick_split(chain, true) : nullptr;
+    Split_Kernel * walking = nullptr;
+    long long const walkers = split_walkers(chain, stream_count, max_tiles, min_tiles, &walking);
 
-    if (walking)
+    if (walkers < 0) return hipErrorInvalidValue;
+
+    if (bytes > 48 * 1024)
     {
-        int per_cu = 0, device = 0, cus = 0;
-
-        if (bytes > 48 * 1024)
-        {
-            hipError_t const status = hipFuncSetAttribute(reinterpret_cast<void const *>(walking),
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
-
-            if (status != hipSuccess) return status;
-        }
-
-        if (chain->unit_walk > 0) walkers = chain->unit_walk;
-        else if (max_tiles <= kSplitWalkTiles
-                 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<void const *>(walking), static_cast<int>(threads), bytes) == hipSuccess
-                 && hipGetDevice(&device) == hipSuccess
-                 && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess)
-        {
-            walkers = static_cast<long long>(per_cu) * cus;
-        }
-
-        if (walkers >= pairs) walkers = 0;   // (a workgroup per unit: nothing to walk)
-    }
-
-    if (walkers <= 0 && bytes > 48 * 1024)
-    {
-        hipError_t const status = hipFuncSetAttribute(reinterpret_cast<void const *>(split),
+        hipError_t const status = hipFuncSetAttribute(reinterpret_cast<void const *>(walkers > 0 ? walking : split),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
 
         if (status != hipSuccess) return status;

@@ -390,8 +390,11 @@ def measure(name, arithmetic, streams, seconds, steps, warmup, rank, world, loca
     mean_samples = sum(samples) / len(samples)
     result["roofline"] = roofline_of(info, fast, mean_samples, mean_kernel, mean_step)
     if fast and info.fast_collapsed and mean_samples / (streams * ch) <= 2 * info.fast_tile_frames:
-        # steps of a tile or two per stream run the staged kernels (drb_batch.c)
-        result["roofline"]["kernel"] = "drb_fast_kernel (steps of at most two tiles per stream)"
+        # steps of a tile or two per stream: the split kernel with workgroups that go from stream
+        # to stream where the streams run in step, else the staged kernels (drb_batch.c)
+        walkers = batch.step_walkers()
+        result["roofline"]["kernel"] = ("drb_split_kernel (%d workgroups going from stream to stream)" % walkers if walkers
+                                        else "drb_fast_kernel (steps of at most two tiles per stream)")
     result["dtype"] = ("f32 products from pairs of f16 halves" if fast and info.fast_issued_half_flops_per_output_sample > 0
                        else "f32")
     result["config"] = {

@@ -2,7 +2,7 @@ set -o pipefail
 mkdir -p gpurun_out/u01
 timeout -k 10 600 python3 -u -m pytest tests/test_gpu_fast.py -m gpu -x -q --timeout 120 --timeout-method thread ${PYTEST_ARGS:--k "stream_to_stream or many_tiles"} > gpurun_out/u01/pytest.log 2>&1 || { tail -40 gpurun_out/u01/pytest.log; exit 1; }
 tail -1 gpurun_out/u01/pytest.log
-for apart in default 0; do
+for apart in ${APARTS:-default 0 1}; do
 if [ $apart = default ]; then unset DRB_AMD_FAST_APART; else export DRB_AMD_FAST_APART=$apart; fi
 DRB_AMD_HOST_PROFILE=1 timeout -k 10 200 python3 bench.py --call-frames 4096 --steps 3 --warmup 1 --no-host-fed --no-cpu-baseline --no-configs > gpurun_out/u01/short_$apart.json 2> gpurun_out/u01/short_$apart.err || { tail gpurun_out/u01/short_$apart.err; exit 1; }
 python3 -c '
