@@ -287,6 +287,20 @@ static DrbAmd_Status resolve (DrbAmd_Batch_Config const * config, Drb_Plan * pla
  * some launch has no kernel (fast arithmetic then runs the cascade kernel). */
 static int make_launches (DrbAmd_Batch_Config const * config, Drb_Plan const * plan, int const * first, int const * last, int count, Fast_Launch * launches);
 
+/* why the last build_launches on this thread found no matrix-core launches ("" where it found them) */
+static _Thread_local char launches_why [96];
+
+static int no_launches (char const * format, ...)
+{
+    va_list arguments;
+
+    va_start(arguments, format);
+    vsnprintf(launches_why, sizeof(launches_why), format, arguments);
+    va_end(arguments);
+
+    return 0;
+}
+
 static int build_launches (DrbAmd_Batch_Config const * config, Drb_Plan const * plan, Fast_Launch * launches)
 {
     int sinc = -1, count = 0;
@@ -295,8 +309,10 @@ static int build_launches (DrbAmd_Batch_Config const * config, Drb_Plan const * 
      * above 2^-7 of full scale, so "within one step of upstream" means the same
      * float32 bit for bit.  Only the exact kernels deliver that: fast arithmetic
      * on int32 buffers runs them. */
-    if (config->sample_type == drb_amd_sample_i32) return 0;
-    if (config->arithmetic != drb_amd_arithmetic_fast) return 0;
+    launches_why[0] = 0;
+
+    if (config->sample_type == drb_amd_sample_i32) return no_launches("int32 samples: one step of theirs is a float32's last bit");
+    if (config->arithmetic != drb_amd_arithmetic_fast) return no_launches("exact arithmetic asked for");
 
     int first [max_launches], last [max_launches];
 
@@ -336,7 +352,7 @@ static int build_launches (DrbAmd_Batch_Config const * config, Drb_Plan const * 
         }
     }
 
-    if (count < 1 || count > max_launches) return 0;
+    if (count < 1 || count > max_launches) return no_launches("%d launches", count);
 
     /* Interpolators in front of the sinc stage's launch: folded into its filter where
      * the split kernel takes the longer chain (the rates in between then never
@@ -366,6 +382,8 @@ static int build_launches (DrbAmd_Batch_Config const * config, Drb_Plan const * 
             if (made > 0) return made;
         }
     }
+
+    launches_why[0] = 0;
 
     return make_launches(config, plan, first, last, count, launches);
 }
@@ -402,7 +420,7 @@ static int make_launches (DrbAmd_Batch_Config const * config, Drb_Plan const * p
                 if (part.stages[k].kind == drb_stage_down2x) launch->halves = 1;
             }
 
-            if (!launch->doubles && !launch->halves) return 0;   /* a slicer alone: re-blocking, no filter */
+            if (!launch->doubles && !launch->halves) return no_launches("launch %d of %d: a slicer alone", i + 1, count);   /* re-blocking, no filter */
         }
 
         drb_plan_geometry(&part, lds_budget, &geometry);
@@ -426,7 +444,12 @@ static int make_launches (DrbAmd_Batch_Config const * config, Drb_Plan const * p
         int const folded = launch->fast.pre_ups > 0;
         int const staged_ok = !folded && drb_hip_fast_kernel_exists(&launch->fast);
 
-        if (!launch->fast.usable) return 0;
+        if (!launch->fast.usable)
+        {
+            return no_launches("launch %d of %d (%s): no tile geometry (segment %d -> %d frames, lookback %d)", i + 1, count,
+                               launch->has_sinc ? "sinc" : launch->doubles ? "up2x" : "down2x",
+                               launch->fast.seg_x, launch->fast.seg_y, launch->fast.look_x);
+        }
 
         /* [up] sinc [down] as one filter on the half-precision matrix instruction
          * where that form applies and its kernel fits (DRB_AMD_FAST_SPLIT=0, a
@@ -453,7 +476,13 @@ static int make_launches (DrbAmd_Batch_Config const * config, Drb_Plan const * p
             }
         }
 
-        if (launch->fast.kind != 4 && !staged_ok) return 0;
+        if (launch->fast.kind != 4 && !staged_ok)
+        {
+            return no_launches("launch %d of %d (%s): no kernel image (up %d, sinc %d steps, down %d taps; segment %d -> %d)", i + 1, count,
+                               launch->has_sinc ? "sinc" : launch->doubles ? "up2x" : "down2x",
+                               launch->fast.has_up ? launch->fast.up_taps : 0, launch->fast.ksteps,
+                               launch->fast.has_down ? launch->fast.down_taps : 0, launch->fast.seg_x, launch->fast.seg_y);
+        }
     }
 
     return count;
@@ -558,6 +587,8 @@ DrbAmd_Status drb_amd_plan_info (DrbAmd_Batch_Config const * config, DrbAmd_Plan
 
         snprintf(info->kernel_name, sizeof(info->kernel_name), "%s", name);
     }
+
+    snprintf(info->fast_why_not, sizeof(info->fast_why_not), "%s", count > 0 ? "" : launches_why);
 
     counted_free(launches);
 

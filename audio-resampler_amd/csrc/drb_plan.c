@@ -1039,6 +1039,9 @@ int drb_plan_collapse_geometry (Drb_Fast_Chain * chain, int lds_budget_bytes, in
          * whose plane is a straight copy of the source) */
         if (c.pre_ups > 0 && !((seg_u >> ups) & 1)) continue;
         if (seg_y < 128) continue;
+        /* (an even source segment makes a padded plane, which takes segments of 128 frames
+         * and more: a shorter even one would be chosen for nothing) */
+        if (!((seg_u >> ups) & 1) && (seg_u >> ups) < 128) continue;
 
         int const blocks = (seg_y + 15) / 16;
         double const fill = (double)seg_y / (16.0 * blocks) * (blocks <= drb_split_max_blocks ? 1.0 : 0.01);

@@ -52,7 +52,8 @@ class PlanInfo(ctypes.Structure):
                 ("bytes_per_output_sample", ctypes.c_double),
                 ("fast_path", ctypes.c_int), ("fast_tile_frames", ctypes.c_int), ("fast_launches", ctypes.c_int),
                 ("fast_issued_flops_per_output_sample", ctypes.c_double), ("fast_collapsed", ctypes.c_int),
-                ("fast_issued_half_flops_per_output_sample", ctypes.c_double), ("kernel_name", ctypes.c_char * 48)]
+                ("fast_issued_half_flops_per_output_sample", ctypes.c_double), ("kernel_name", ctypes.c_char * 48),
+                ("fast_why_not", ctypes.c_char * 96)]
 
     def stages(self):
         kinds = {1: "up2x", 2: "down2x", 3: "sinc", 4: "slicer"}

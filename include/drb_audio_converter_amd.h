@@ -403,6 +403,9 @@ typedef struct DrbAmd_Plan_Info
                                instruction's rate)                                 */
     char kernel_name [48];  /* the kernel that does most of the work of a step in
                                the configuration's arithmetic mode                 */
+    char fast_why_not [96]; /* fast_path 0: what kept the configuration from the
+                               matrix-core kernels (which launch of its chain, and
+                               what that launch lacks); "" where fast_path is 1   */
 }
 DrbAmd_Plan_Info;
 

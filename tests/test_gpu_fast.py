@@ -450,3 +450,75 @@ def test_workgroups_that_go_from_stream_to_stream(case, monkeypatch):
         else:
             assert_close(got, want, "%s stream %d" % (name, s))
     runner.close()
+
+
+DOWN_BY_THREE_QUARTERS = [
+    # src, dst, quality, sample, layout: chains whose fractional stage goes 3 -> 4 (96 -> 128 kHz and the
+    # like) in front of one to four decimators.  Planar float32: the buffers between a chain's launches
+    # are that, and the split kernel takes a launch whose source and target have one format.
+    (48000, 16000, support.FINE, "f32", "planar"),
+    (48000, 16000, support.GOOD, "f32", "planar"),
+    (48000, 16000, support.BEST, "f32", "planar"),
+    (48000, 8000, support.GOOD, "f32", "planar"),       # (ran the staged kernels for this launch before)
+    (96000, 16000, support.GOOD, "f32", "planar"),
+    (96000, 8000, support.FINE, "f32", "planar"),
+    (192000, 16000, support.GOOD, "f32", "planar"),
+    (192000, 16000, support.BEST, "f32", "planar"),
+]
+
+
+@pytest.mark.parametrize("src,dst,quality,sample,layout", DOWN_BY_THREE_QUARTERS)
+def test_fast_mode_segments_chosen_for_the_split_kernel(src, dst, quality, sample, layout):
+    """48 / 96 / 192 kHz down to 8 / 16 kHz: the launch with the fractional stage has
+    segments of 3 k source and 4 k target frames.  The fullest segment, 96 -> 128
+    frames, has an even source length below what a padded plane takes; the planner
+    goes on to 117 -> 156 (odd: a straight plane, ten row blocks), and the chain
+    runs on the matrix cores.  Three streams of two seconds in calls of uneven
+    length against the upstream converter's restatement."""
+    ch = 2
+    sample_type = {"f32": drbamd.F32, "i16": drbamd.I16}[sample]
+    layout_type = drbamd.INTERLEAVED if layout == "interleaved" else drbamd.PLANAR
+    config = drbamd.make_config(src, dst, ch, 256, 16, PUSH, quality, sample_type=sample_type, layout=layout_type,
+                                arithmetic=drbamd.FAST, streams=3)
+    info = drbamd.plan_info(config)
+    assert info.fast_path == 1 and info.fast_collapsed == 2 and info.fast_why_not == b"", info.fast_why_not
+    status, plan = support.oracle_plan(src, dst, ch, 256, 16, PUSH, quality)
+    assert status == 1
+    lengths = [2 * src, int(1.3 * src) // 256 * 256, 2 * src]
+    patterns = [[10 ** 9], [4096 * 7, 256, 4096 * 11], [src // 256 * 256, 4096]]
+    noise = [support.white_noise(ch, lengths[s], 500 + s) for s in range(3)]
+    if sample == "i16":
+        inputs = [np.round(x * 32767).astype(np.int16) for x in noise]
+        floats = [support.oracle_convert_samples(x, "f32") for x in inputs]
+    else:
+        inputs, floats = noise, noise
+    runner = gpu_support.StreamRunner(config, inputs)
+    schedules = [gpu_support.chunk_schedule(lengths[s], patterns[s]) for s in range(3)]
+    for i in range(max(len(s) for s in schedules)):
+        runner.step([s[i] if i < len(s) else 0 for s in schedules])
+    for s in range(3):
+        got = runner.result(s)
+        want = support.oracle_push(plan, floats[s])
+        assert got.shape == want.shape, (s, got.shape, want.shape)
+        if sample == "i16":
+            want_q = support.oracle_convert_samples(np.ascontiguousarray(want), "i16")
+            assert np.abs(got.astype(np.int64) - want_q.astype(np.int64)).max() <= 1, s
+        else:
+            assert_close(got, want, "stream %d" % s)
+    runner.close()
+
+
+def test_plan_info_says_what_keeps_a_chain_from_the_matrix_cores():
+    """A configuration that runs the exact kernels in fast arithmetic says why: which launch
+    of its chain, and what that launch lacks."""
+    cases = [
+        (8000, 11025, support.GOOD, drbamd.F32, b"no tile geometry"),      # a period of 441 target frames
+        (22050, 48000, support.POOR, drbamd.F32, b"no kernel image"),      # 147 -> 320 with one up-sampler
+        (44100, 48000, support.GOOD, drbamd.I32, b"int32 samples"),
+    ]
+    for src, dst, quality, sample_type, text in cases:
+        config = drbamd.make_config(src, dst, 2, 256, 16, PUSH, quality, sample_type=sample_type, arithmetic=drbamd.FAST, streams=2)
+        info = drbamd.plan_info(config)
+        assert info.fast_path == 0 and text in info.fast_why_not, (src, dst, info.fast_why_not)
+    config = drbamd.make_config(44100, 48000, 2, 256, 16, PUSH, support.GOOD, arithmetic=drbamd.FAST, streams=2)
+    assert drbamd.plan_info(config).fast_why_not == b""
