@@ -522,3 +522,59 @@ def test_plan_info_says_what_keeps_a_chain_from_the_matrix_cores():
         assert info.fast_path == 0 and text in info.fast_why_not, (src, dst, info.fast_why_not)
     config = drbamd.make_config(44100, 48000, 2, 256, 16, PUSH, support.GOOD, arithmetic=drbamd.FAST, streams=2)
     assert drbamd.plan_info(config).fast_why_not == b""
+
+
+FOLDED_FORMATS = [
+    # src, dst, quality, sample, layout, direction: chains of interpolators folded into the one filter,
+    # in the buffer formats other than planar float32
+    (16000, 48000, support.GOOD, "i16", "interleaved", PUSH),
+    (16000, 48000, support.GOOD, "i16", "interleaved", PULL),
+    (8000, 48000, support.GOOD, "f32", "interleaved", PUSH),
+    (8000, 48000, support.FINE, "f32", "interleaved", PULL),
+    (16000, 96000, support.FINE, "i16", "planar", PUSH),
+    (8000, 96000, support.POOR, "i16", "interleaved", PUSH),
+]
+
+
+@pytest.mark.parametrize("src,dst,quality,sample,layout,direction", FOLDED_FORMATS)
+def test_fast_mode_folded_interpolators_in_every_buffer_format(src, dst, quality, sample, layout, direction):
+    """8 / 16 kHz up to 48 / 96 kHz run as one launch, the interpolators folded into the
+    fractional stage's filter, with tiles of 4 or 6 wave-wide loads; those kernel
+    images exist for int16 and interleaved buffers as they do for planar float32.
+    Three stereo streams of uneven length in calls of uneven length."""
+    ch = 2
+    sample_type = {"f32": drbamd.F32, "i16": drbamd.I16}[sample]
+    layout_type = drbamd.INTERLEAVED if layout == "interleaved" else drbamd.PLANAR
+    config = drbamd.make_config(src, dst, ch, 256, 16, direction, quality, sample_type=sample_type, layout=layout_type,
+                                arithmetic=drbamd.FAST, streams=3)
+    info = drbamd.plan_info(config)
+    assert info.fast_path == 1 and info.fast_collapsed == 2 and info.fast_launches == 1, info.fast_why_not
+    status, plan = support.oracle_plan(src, dst, ch, 256, 16, direction, quality)
+    assert status == 1
+    user_rate = dst if direction == PULL else src
+    lengths = [2 * user_rate // 256 * 256, int(1.3 * user_rate) // 256 * 256, 2 * user_rate // 256 * 256]
+    patterns = [[10 ** 9], [4096 * 3, 256, 4096 * 5], [user_rate // 256 * 256, 4096]]
+    need = max(lengths) if direction == PUSH else int(max(lengths) * src / dst) + 65536
+    noise = [support.white_noise(ch, need, 600 + s) for s in range(3)]
+    if sample == "i16":
+        inputs = [np.round(x * 32767).astype(np.int16) for x in noise]
+        floats = [support.oracle_convert_samples(x, "f32") for x in inputs]
+    else:
+        inputs, floats = noise, noise
+    runner = gpu_support.StreamRunner(config, inputs)
+    schedules = [gpu_support.chunk_schedule(lengths[s], patterns[s]) for s in range(3)]
+    for i in range(max(len(s) for s in schedules)):
+        runner.step([s[i] if i < len(s) else 0 for s in schedules])
+    for s in range(3):
+        got = runner.result(s)
+        if direction == PUSH:
+            want = support.oracle_push(plan, floats[s][:, :lengths[s]])
+        else:
+            want, _ = support.oracle_pull(plan, floats[s], lengths[s])
+        assert got.shape == want.shape, (s, got.shape, want.shape)
+        if sample == "i16":
+            want_q = support.oracle_convert_samples(np.ascontiguousarray(want), "i16")
+            assert np.abs(got.astype(np.int64) - want_q.astype(np.int64)).max() <= 1, s
+        else:
+            assert_close(got, want, "stream %d" % s)
+    runner.close()
