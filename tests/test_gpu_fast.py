@@ -542,13 +542,40 @@ def test_fast_mode_folded_interpolators_in_every_buffer_format(src, dst, quality
     fractional stage's filter, with tiles of 4 or 6 wave-wide loads; those kernel
     images exist for int16 and interleaved buffers as they do for planar float32.
     Three stereo streams of uneven length in calls of uneven length."""
+    three_streams_against_the_oracle(src, dst, quality, sample, layout, direction, launches=1)
+
+
+FIRST_LAUNCH_CONVERTS = [
+    # src, dst, quality, sample, layout, direction, launches: decimating chains whose first launch (the one
+    # with the fractional stage) reads the caller's format and hands planar float32 to the decimators behind it
+    (48000, 16000, support.GOOD, "i16", "interleaved", PUSH, 3),
+    (192000, 44100, support.BEST, "i16", "interleaved", PUSH, 3),    # (ran the staged kernels for that launch before)
+    (96000, 22050, support.GOOD, "i16", "interleaved", PUSH, 3),     # (the same)
+    (48000, 22050, support.GOOD, "f32", "interleaved", PUSH, 2),
+    (88200, 48000, support.FINE, "i16", "planar", PUSH, 2),
+    (96000, 44100, support.GOOD, "i16", "interleaved", PULL, 2),
+    (176400, 48000, support.BEST, "f32", "interleaved", PUSH, 3),
+    (48000, 11025, support.BEST, "i16", "interleaved", PULL, 3),
+]
+
+
+@pytest.mark.parametrize("src,dst,quality,sample,layout,direction,launches", FIRST_LAUNCH_CONVERTS)
+def test_fast_mode_first_launch_reads_the_callers_format(src, dst, quality, sample, layout, direction, launches):
+    """A chain of several launches keeps planar float32 between them.  The split kernel
+    of its first launch loads int16 or interleaved samples as that format's kernel
+    does and stores planar float32 (16-bit samples scaled back by a power of two);
+    the last launch, a decimator, stores the caller's format."""
+    three_streams_against_the_oracle(src, dst, quality, sample, layout, direction, launches=launches)
+
+
+def three_streams_against_the_oracle(src, dst, quality, sample, layout, direction, launches):
     ch = 2
     sample_type = {"f32": drbamd.F32, "i16": drbamd.I16}[sample]
     layout_type = drbamd.INTERLEAVED if layout == "interleaved" else drbamd.PLANAR
     config = drbamd.make_config(src, dst, ch, 256, 16, direction, quality, sample_type=sample_type, layout=layout_type,
                                 arithmetic=drbamd.FAST, streams=3)
     info = drbamd.plan_info(config)
-    assert info.fast_path == 1 and info.fast_collapsed == 2 and info.fast_launches == 1, info.fast_why_not
+    assert info.fast_path == 1 and info.fast_collapsed == 2 and info.fast_launches == launches, (info.fast_launches, info.fast_why_not)
     status, plan = support.oracle_plan(src, dst, ch, 256, 16, direction, quality)
     assert status == 1
     user_rate = dst if direction == PULL else src
