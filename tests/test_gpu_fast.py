@@ -263,18 +263,24 @@ def test_fast_mode_ragged_streams_with_a_reset(src, dst, ch, direction, n, most)
     runner.close()
 
 
-@pytest.mark.parametrize("src,dst,quality", [(176400, 192000, support.POOR), (192000, 176400, support.BEST)])
-def test_fast_mode_one_long_step_of_few_streams_on_the_staged_kernels(src, dst, quality):
+@pytest.mark.parametrize("src,dst,quality,kernel", [(176400, 192000, support.POOR, b"drb_fast_kernel"),
+                                                    (176400, 192000, support.POOR, b"drb_split_kernel"),
+                                                    (192000, 176400, support.BEST, b"drb_fast_kernel")])
+def test_fast_mode_one_long_step_of_few_streams_on_the_staged_kernels(src, dst, quality, kernel, monkeypatch):
     """Few streams and one long step: a stream's tiles are dealt out to many
     workgroups, each of which builds its coefficients per tile; 176.4 <-> 192 kHz
     drifts 2.6 times as fast as 44.1 -> 48 kHz (coefficients built for a tile
-    far from the one they were used on came to 6.9e-6 of error here)."""
+    far from the one they were used on came to 6.9e-6 of error here).  A lone
+    fractional stage (poor quality) runs the split kernel unless told otherwise:
+    both are held to the same margin."""
     ch, frames = 2, 450000
+    if quality == support.POOR and kernel == b"drb_fast_kernel":
+        monkeypatch.setenv("DRB_AMD_FAST_LONE", "0")
     status, plan = support.oracle_plan(src, dst, ch, 256, 16, PUSH, quality)
     assert status == 1
     config = drbamd.make_config(src, dst, ch, 256, 16, PUSH, quality, arithmetic=drbamd.FAST, streams=2)
     info = drbamd.plan_info(config)
-    assert info.fast_path == 1 and info.kernel_name == b"drb_fast_kernel"
+    assert info.fast_path == 1 and info.kernel_name == kernel
     inputs = [support.white_noise(ch, frames, 41 + s) for s in range(2)]
     runner = gpu_support.StreamRunner(config, inputs)
     runner.step([frames, frames - 4096])

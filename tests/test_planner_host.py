@@ -111,9 +111,9 @@ def test_which_kernels_a_configuration_gets():
     assert headline.kernel_name == b"drb_split_kernel" and headline.fast_tile_frames == 16 * 160
     assert headline.fast_issued_half_flops_per_output_sample == headline.fast_issued_flops_per_output_sample > 0
 
-    # one stage: nothing to fold, the staged kernel
+    # one stage: nothing to fold, and still the split kernel (the faster one for it as well)
     poor = info(44100, 48000, 2, support.PUSH, support.POOR, **fast)
-    assert (poor.fast_path, poor.fast_collapsed) == (1, 0) and poor.kernel_name == b"drb_fast_kernel"
+    assert (poor.fast_path, poor.fast_collapsed) == (1, 2) and poor.kernel_name == b"drb_split_kernel"
 
     # a lone half-band decimator
     cfg3 = info(96000, 48000, 8, support.PUSH, support.GOOD, **fast)
