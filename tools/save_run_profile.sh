@@ -17,7 +17,7 @@ reads, writes = per_dispatch("TCC_EA0_RDREQ_sum"), per_dispatch("TCC_EA0_WRREQ_s
 read_gb, written_gb = reads * 64 * 2 / 1e9, writes * 64 / 1e9
 header = """rocprofv3 --pmc passes of `python3 bench.py --steps 20 --warmup 15 --no-cpu-baseline --no-host-fed --no-configs` (tools/run_profile.sh),
 one pass per block of counters.  In every block the groups are: drb_table_kernel (44 dispatches); an unnamed group of 88 dispatches =
-drb_collapse_build_kernel + drb_history_kernel together; and "void" (44 dispatches) = drb_split_kernel<4, 10, 0, false, false>, the
+drb_collapse_build_kernel + drb_history_kernel together; and "void" (44 dispatches) = drb_split_kernel<4, 10, 0, false, false, false>, the
 headline's filter kernel.
 HBM traffic per launch of the split kernel: TCC_EA0_RDREQ_sum %s x 64 B x 2 (gfx950 tallies the 128-B requests of
 16-B-per-lane streaming reads at 64 B) = %.3f GB read; TCC_EA0_WRREQ_sum %s x 64 B = %.3f GB written;
