@@ -896,34 +896,63 @@ DrbAmd_Status drb_amd_batch_reset (DrbAmd_Batch * batch, int first, int count)
 
     int code = drb_hip_set_device(batch->device);
 
-    /* earlier steps may still be reading the history */
-    for (int i = 0; i < ring_slots && !code; i++)
+    /* Earlier steps may still be reading the histories, and later ones must find them
+     * cleared: the clearing goes on the stream of the batch's last step, behind it.  A
+     * step on another stream waits for that step's event, which is recorded again behind
+     * the clearing.  Nothing waits on the host (a pull converter that starts over before
+     * every step would otherwise never have two steps in flight).  A batch that has
+     * nothing in flight clears on the null stream and waits for that. */
+    int pending = 0;
+
+    for (int i = 0; i < ring_slots; i++) pending |= batch->slot_pending[i];
+
+    int ordered = pending && batch->last_slot >= 0 && batch->slot_pending[batch->last_slot];
+
+    /* (twice at most: a caller may have waited for its stream itself and destroyed it
+     * since; the clearing then fails there and is done the other way) */
+    for (int attempt = 0; attempt < 2; attempt++)
     {
-        if (batch->slot_pending[i])
+        void * const hip_stream = ordered ? batch->last_stream : 0;
+
+        if (!ordered)
         {
-            code = drb_hip_event_synchronize(batch->slot_done[i]);
-            batch->slot_pending[i] = 0;
+            for (int i = 0; i < ring_slots && !code; i++)
+            {
+                if (batch->slot_pending[i])
+                {
+                    code = drb_hip_event_synchronize(batch->slot_done[i]);
+                    batch->slot_pending[i] = 0;
+                }
+            }
         }
-    }
 
-    size_t const per_stream = (size_t)batch->plan.channels * batch->geometry.history_frames * sizeof(float);
-
-    for (int i = 0; i < 2 && !code; i++)
-    {
-        code = drb_hip_memset_async((char *)batch->history[i] + first * per_stream, 0, count * per_stream, 0);
-    }
-
-    for (int l = 1; l < batch->launch_count && !code; l++)
-    {
-        size_t const each = (size_t)batch->plan.channels * batch->launches[l].chain.history * sizeof(float);
+        size_t const per_stream = (size_t)batch->plan.channels * batch->geometry.history_frames * sizeof(float);
 
         for (int i = 0; i < 2 && !code; i++)
         {
-            code = drb_hip_memset_async((char *)batch->launches[l].history[i] + first * each, 0, count * each, 0);
+            code = drb_hip_memset_async((char *)batch->history[i] + first * per_stream, 0, count * per_stream, hip_stream);
         }
+
+        for (int l = 1; l < batch->launch_count && !code; l++)
+        {
+            size_t const each = (size_t)batch->plan.channels * batch->launches[l].chain.history * sizeof(float);
+
+            for (int i = 0; i < 2 && !code; i++)
+            {
+                code = drb_hip_memset_async((char *)batch->launches[l].history[i] + first * each, 0, count * each, hip_stream);
+            }
+        }
+
+        if (!code && ordered) code = drb_hip_event_record(batch->slot_done[batch->last_slot], hip_stream);
+        if (!code && !ordered) code = drb_hip_stream_synchronize(0);
+
+        if (!code || !ordered) break;
+
+        drb_hip_clear_error();
+        ordered = 0;
+        code = 0;
     }
 
-    if (!code) code = drb_hip_stream_synchronize(0);
     if (code) return fail_hip("history reset", code);
 
     for (int s = first; s < first + count; s++) drb_stream_reset(&batch->plan, &batch->states[s]);

@@ -179,6 +179,7 @@ int drb_hip_alloc (void ** pointer, size_t bytes);
 int drb_hip_free (void * pointer);
 int drb_hip_host_alloc (void ** pointer, size_t bytes);
 int drb_hip_host_free (void * pointer);
+void drb_hip_clear_error (void);
 int drb_hip_memset_async (void * pointer, int value, size_t bytes, void * stream);
 int drb_hip_upload_async (void * device, void const * host, size_t bytes, void * stream);
 /* the same for up to three small tables in pinned host memory (hipHostMalloc), fetched by one kernel instead of DMA engines */

@@ -788,6 +788,12 @@ int drb_hip_free (void * pointer) { allocation_calls.fetch_add(1); return hipFre
 int drb_hip_host_alloc (void ** pointer, size_t bytes) { allocation_calls.fetch_add(1); return hipHostMalloc(pointer, bytes, hipHostMallocDefault); }
 int drb_hip_host_free (void * pointer) { allocation_calls.fetch_add(1); return hipHostFree(pointer); }
 
+// forgets the calling thread's last HIP error (a call that failed on purpose-built grounds, and was made good otherwise)
+void drb_hip_clear_error (void)
+{
+    (void)hipGetLastError();
+}
+
 int drb_hip_memset_async (void * pointer, int value, size_t bytes, void * stream)
 {
     return hipMemsetAsync(pointer, value, bytes, static_cast<hipStream_t>(stream));

@@ -222,7 +222,10 @@ extern DrbAmd_Status drb_amd_batch_create (DrbAmd_Batch_Config const * config, D
 extern void drb_amd_batch_destroy (DrbAmd_Batch * batch);
 
 /* Returns every stream (or streams [first, first + count)) to its
- * just-constructed state: zero history, initial phase. */
+ * just-constructed state: zero history, initial phase.  Does not wait for the
+ * device: while steps of the batch are in flight the histories are cleared on
+ * the HIP stream of the most recent step, behind it, and the next step, on
+ * whatever stream, comes behind that. */
 extern DrbAmd_Status drb_amd_batch_reset (DrbAmd_Batch * batch, int first, int count);
 
 /* Frame counts the next process call would yield, without changing state.
