@@ -879,8 +879,8 @@ void drb_amd_batch_destroy (DrbAmd_Batch * batch)
 
     if (getenv("DRB_AMD_HOST_PROFILE") && host_steps > 0)
     {
-        fprintf(stderr, "host us per step: frame arithmetic %.1f, descriptors %.1f, coefficient jobs + uploads %.1f, launches %.1f (%ld steps)\n",
-                host_spent[0] / host_steps, host_spent[1] / host_steps, host_spent[2] / host_steps, host_spent[3] / host_steps, host_steps);
+        fprintf(stderr, "host us per step: frame arithmetic %.1f, descriptors %.1f, coefficient jobs + uploads %.1f, launches %.1f, waiting for a step slot %.1f (%ld steps)\n",
+                host_spent[0] / host_steps, host_spent[1] / host_steps, host_spent[2] / host_steps, host_spent[3] / host_steps, host_spent[4] / host_steps, host_steps);
     }
 
     drb_hip_set_device(batch->device);
@@ -1251,11 +1251,15 @@ DrbAmd_Status drb_amd_batch_process
     /* phase 2: descriptors -> device, launch */
     int const slot = batch->slot;
 
+    HOST_MARK(1);
+
     if (batch->slot_pending[slot])
     {
         if ((code = drb_hip_event_synchronize(batch->slot_done[slot])) != 0) return fail_hip("hipEventSynchronize", code);
         batch->slot_pending[slot] = 0;
     }
+
+    HOST_MARK(4);   /* waiting for one of the ring's step slots: the device's time, not the host's */
 
     Drb_Device_Call * const calls = batch->calls_host[slot];
     int const fast = batch->config.arithmetic == drb_amd_arithmetic_fast && batch->launch_count > 0;
@@ -1896,6 +1900,21 @@ int drb_amd_batch_step_groups (DrbAmd_Batch const * batch)
 int drb_amd_batch_step_walkers (DrbAmd_Batch const * batch)
 {
     return batch ? batch->step_walkers : 0;
+}
+
+long drb_amd_host_times (double microseconds [5], int start_over)
+{
+    long const steps = host_steps;
+
+    for (int i = 0; i < 5; i++)
+    {
+        if (microseconds) microseconds[i] = host_spent[i];
+        if (start_over) host_spent[i] = 0.0;
+    }
+
+    if (start_over) host_steps = 0;
+
+    return steps;
 }
 
 #ifdef DRB_FAST_STAMPS

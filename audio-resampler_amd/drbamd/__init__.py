@@ -90,6 +90,9 @@ if hasattr(lib, "drb_amd_batch_step_groups"):
     lib.drb_amd_batch_step_groups.argtypes = [ctypes.c_void_p]
 if hasattr(lib, "drb_amd_batch_step_walkers"):
     lib.drb_amd_batch_step_walkers.argtypes = [ctypes.c_void_p]
+if hasattr(lib, "drb_amd_host_times"):
+    lib.drb_amd_host_times.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_int]
+    lib.drb_amd_host_times.restype = ctypes.c_long
 if hasattr(lib, "drb_amd_allocation_calls"):
     lib.drb_amd_allocation_calls.restype = ctypes.c_longlong
 lib.drb_amd_plan_info.argtypes = [ctypes.POINTER(BatchConfig), ctypes.POINTER(PlanInfo)]
@@ -128,6 +131,16 @@ def converter_size(src, dst, channels, block_size, max_block_count, direction, q
                                                     direction, quality, ctypes.byref(alignment),
                                                     ctypes.byref(size))
     return (alignment.value, size.value) if ok else None
+
+
+def host_times(start_over=False):
+    """(steps, [microseconds of frame arithmetic, step preparation, jobs and descriptors, launches, waiting for a step slot])
+    spent inside the process calls so far; None where the library has no such call."""
+    if not hasattr(lib, "drb_amd_host_times"):
+        return None
+    spent = (ctypes.c_double * 5)()
+    steps = lib.drb_amd_host_times(spent, 1 if start_over else 0)
+    return steps, list(spent)
 
 
 def plan_describe(config):

@@ -357,8 +357,14 @@ def measure(name, arithmetic, streams, seconds, steps, warmup, rank, world, loca
             step()
         result["host_ms_per_step"] = round((time.perf_counter() - start) / 3 * 1e3, 4)
     else:
+        drbamd.host_times(start_over=True)
         step()
         result["host_ms_per_step"] = round((time.perf_counter() - start) * 1e3, 4)   # includes waits for the device
+        spent = drbamd.host_times()
+        if spent:
+            # what the library's calls themselves took on the host, and what of it was waiting for the device
+            result["host_work_ms_per_step"] = round(sum(spent[1][:4]) * 1e-3, 4)
+            result["host_wait_ms_per_step"] = round(spent[1][4] * 1e-3, 4)
     torch.cuda.synchronize()
 
     # the filter kernels and the whole device side of a step: HIP events on the launch stream
@@ -507,6 +513,9 @@ def main():
         }
         if "host_fed" in main_run:
             line["host_fed"] = main_run["host_fed"]
+        for key in ("host_work_ms_per_step", "host_wait_ms_per_step"):
+            if key in main_run:
+                line[key] = main_run[key]
 
     if single and not args.no_configs and args.workload == "headline" and not args.call_frames and not args.phases_apart:
         configs = []

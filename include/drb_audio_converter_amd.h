@@ -351,6 +351,15 @@ extern DrbAmd_Status drb_amd_batch_kernel_ms (DrbAmd_Batch * batch, float * mill
  * upload, coefficient sets, filter kernels, history update. */
 extern DrbAmd_Status drb_amd_batch_step_ms (DrbAmd_Batch * batch, float * milliseconds);
 
+/* What the host has spent inside drb_amd_batch_process* since the process began (or
+ * since the last call with start_over set), in microseconds, over all batches
+ * (a diagnostic: not kept per thread): [0] frame arithmetic, [1] preparing the
+ * step, [2] coefficient jobs and descriptors, [3] launches, [4] WAITING for one
+ * of a batch's four step slots to come free, which is the device's time: a
+ * host that enqueues steps faster than the device runs them spends its time
+ * there.  Returns the number of steps. */
+extern long drb_amd_host_times (double microseconds [5], int start_over);
+
 /* How often this library has allocated or freed anything so far, on the host or
  * through HIP (device and pinned memory, streams, events): what a caller that
  * may not allocate checks drb_amd_batch_process_dense_static against. */

@@ -85,7 +85,7 @@ def test_library_exports_every_declared_symbol():
              "drb_amd_plan_info",
              "drb_amd_batch_time_kernels", "drb_amd_batch_kernel_ms", "drb_amd_batch_step_ms",
              "drb_amd_plan_describe", "drb_amd_last_error",
-             "drb_amd_allocation_calls", "drb_amd_batch_step_groups", "drb_amd_batch_step_walkers"]
+             "drb_amd_allocation_calls", "drb_amd_batch_step_groups", "drb_amd_batch_step_walkers", "drb_amd_host_times"]
     import re
     header = open(support.ROOT + "/include/drb_audio_converter_amd.h").read()
     declared = set(re.findall(r"\b(drb_a\w+)\s*\n?\s*\(", header))
