@@ -44,7 +44,16 @@ typedef struct Collapse_Group
     int first_job, job_count;         /* in the step's job table; a stretch's job index counts from first_job */
 }
 Collapse_Group;
-static size_t const static_host_bytes = (size_t)256 << 10;       /* pinned, per ring slot, from creation on */
+/* pinned, per ring slot, from creation on: the stretch table and jobs of any step of a few
+ * streams, of a modest step of many (a batch of one stream, which is what the
+ * drop-in converters are, does not pin a megabyte it can never fill) */
+static size_t static_host_bytes_for (size_t streams)
+{
+    size_t const wanted = ((size_t)16 << 10) + streams * ((size_t)4 << 10);
+    size_t const most = (size_t)256 << 10;
+
+    return wanted < most ? wanted : most;
+}
 
 typedef struct Fast_Launch
 {
@@ -99,6 +108,11 @@ struct DrbAmd_Batch
 
     int * fault_device;
     int * fault_host;                 /* pinned                                */
+    /* One block of pinned memory per batch holds the fault word, the ring's step
+     * descriptors and its tables (a process has some 65 000 memory mappings, and every
+     * pinned allocation is one: nine of them per batch ended at 7 271 batches). */
+    void * pinned_block;
+    int collapse_host_own [ring_slots];   /* 1: collapse_host[i] outgrew the block and is an allocation of its own */
 
     /* host-fed entry: three slices of streams in flight */
     void * feed_streams [3];          /* copy in, convert, copy out            */
@@ -645,7 +659,7 @@ static void release (DrbAmd_Batch * batch)
             if (batch->slot_pending[i]) drb_hip_event_synchronize(batch->slot_done[i]);
             drb_hip_event_destroy(batch->slot_done[i]);
         }
-        if (batch->calls_host[i]) drb_hip_host_free(batch->calls_host[i]);
+        batch->calls_host[i] = 0;   /* (in the batch's pinned block) */
     }
 
     for (int i = 0; i < host_slots; i++)
@@ -666,7 +680,7 @@ static void release (DrbAmd_Batch * batch)
         if (batch->launches[i].output) drb_hip_free(batch->launches[i].output);
     }
 
-    for (int i = 0; i < ring_slots; i++) if (batch->collapse_host[i]) drb_hip_host_free(batch->collapse_host[i]);
+    for (int i = 0; i < ring_slots; i++) if (batch->collapse_host[i] && batch->collapse_host_own[i]) drb_hip_host_free(batch->collapse_host[i]);
 
     if (batch->collapse_jobs) drb_hip_free(batch->collapse_jobs);
     if (batch->collapse_spots) drb_hip_free(batch->collapse_spots);
@@ -681,7 +695,7 @@ static void release (DrbAmd_Batch * batch)
     if (batch->history[1]) drb_hip_free(batch->history[1]);
     if (batch->calls_device) drb_hip_free(batch->calls_device);
     if (batch->fault_device) drb_hip_free(batch->fault_device);
-    if (batch->fault_host) drb_hip_host_free(batch->fault_host);
+    if (batch->pinned_block) drb_hip_host_free(batch->pinned_block);
 
     counted_free(batch->states);
     counted_free(batch->trial_states);
@@ -808,13 +822,31 @@ DrbAmd_Status drb_amd_batch_create (DrbAmd_Batch_Config const * config, DrbAmd_B
     if (!code) code = drb_hip_alloc((void **)&batch->history[1], history_bytes);
     if (!code) code = drb_hip_alloc((void **)&batch->calls_device, n * max_launches * sizeof(Drb_Device_Call));
     if (!code) code = drb_hip_alloc((void **)&batch->fault_device, fault_words * sizeof(long long));
-    if (!code) code = drb_hip_host_alloc((void **)&batch->fault_host, sizeof(int));
 
-    for (int i = 0; i < ring_slots && !code; i++)
+    /* pinned: the fault word, then per ring slot the step descriptors, then per ring slot
+     * the tables every step of a modest size fits (a call that may not allocate
+     * finds them there) */
+    size_t const calls_bytes = (n * max_launches * sizeof(Drb_Device_Call) + 255) / 256 * 256;
+    size_t const tables_bytes = static_host_bytes_for(n);
+
+    if (!code) code = drb_hip_host_alloc(&batch->pinned_block, 256 + ring_slots * (calls_bytes + tables_bytes));
+
+    if (!code)
     {
-        code = drb_hip_host_alloc((void **)&batch->calls_host[i], n * max_launches * sizeof(Drb_Device_Call));
-        if (!code) code = drb_hip_event_create(&batch->slot_done[i]);
+        char * const block = batch->pinned_block;
+
+        batch->fault_host = (int *)block;
+
+        for (int i = 0; i < ring_slots; i++)
+        {
+            batch->calls_host[i] = (Drb_Device_Call *)(block + 256 + (size_t)i * calls_bytes);
+            batch->collapse_host[i] = block + 256 + ring_slots * calls_bytes + (size_t)i * tables_bytes;
+            batch->collapse_host_bytes[i] = tables_bytes;
+            batch->collapse_host_own[i] = 0;
+        }
     }
+
+    for (int i = 0; i < ring_slots && !code; i++) code = drb_hip_event_create(&batch->slot_done[i]);
 
     for (int i = 1; i < batch->launch_count && !code; i++)
     {
@@ -822,14 +854,6 @@ DrbAmd_Status drb_amd_batch_create (DrbAmd_Batch_Config const * config, DrbAmd_B
 
         code = drb_hip_alloc((void **)&batch->launches[i].history[0], bytes);
         if (!code) code = drb_hip_alloc((void **)&batch->launches[i].history[1], bytes);
-    }
-
-    /* tables every step of a modest size fits, so that a call that may not
-     * allocate finds them there */
-    for (int i = 0; i < ring_slots && !code; i++)
-    {
-        code = drb_hip_host_alloc(&batch->collapse_host[i], static_host_bytes);
-        if (!code) batch->collapse_host_bytes[i] = static_host_bytes;
     }
 
     if (!code)
@@ -1048,10 +1072,12 @@ static DrbAmd_Status collapse_prepare
     {
         if (batch->no_alloc) return fail(drb_amd_error_capacity, "the step's coefficient tables do not fit the pinned memory the batch was created with");
 
-        if (batch->collapse_host[slot]) drb_hip_host_free(batch->collapse_host[slot]);
+        /* (the slot's share of the batch's pinned block is left where it is) */
+        if (batch->collapse_host[slot] && batch->collapse_host_own[slot]) drb_hip_host_free(batch->collapse_host[slot]);
 
         batch->collapse_host[slot] = 0;
         batch->collapse_host_bytes[slot] = 0;
+        batch->collapse_host_own[slot] = 0;
 
         if ((code = drb_hip_host_alloc(&batch->collapse_host[slot], host_bytes + host_bytes / 2)) != 0)
         {
@@ -1059,6 +1085,7 @@ static DrbAmd_Status collapse_prepare
         }
 
         batch->collapse_host_bytes[slot] = host_bytes + host_bytes / 2;
+        batch->collapse_host_own[slot] = 1;
     }
 
     size_t hash_size = 64;

@@ -14,6 +14,13 @@
  */
 #include HARNESS_API_HEADER
 
+/* Upstream has no destructor: a converter ends with the caller's memory block.  A
+ * library that keeps state of its own per converter names its release function
+ * here (-DHARNESS_RELEASE=...), the one call a maintainer adds when switching. */
+#ifndef HARNESS_RELEASE
+#define HARNESS_RELEASE(converter) ((void)(converter))
+#endif
+
 #include <stdlib.h>
 #include <string.h>
 
@@ -166,6 +173,7 @@ extern long harness_sizes
         );
     }
 
+    if (converter) HARNESS_RELEASE(converter);
     free(memory);
 
     return converter ? size : 0;
@@ -253,6 +261,7 @@ extern long harness_push
         offset += chunks[index];
     }
 
+    HARNESS_RELEASE(converter);
     free(work);
     free(memory);
 
@@ -351,6 +360,7 @@ extern long harness_pull
         offset += chunks[index];
     }
 
+    HARNESS_RELEASE(converter);
     free(work);
     free(memory);
 
