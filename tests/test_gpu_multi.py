@@ -85,6 +85,72 @@ def test_one_batch_fed_from_alternating_streams_keeps_its_order():
     batch.close()
 
 
+def test_streams_started_over_between_steps_on_different_streams():
+    """drb_amd_batch_reset does not wait for the device: it clears the histories on the
+    HIP stream of the batch's most recent step, behind that step, and the next step,
+    on whatever stream, comes behind the clearing.  A long step on one stream, then
+    two of the four streams started over, then a step on another stream with nothing
+    waited for in between: the streams started over equal a fresh converter on the
+    new input, the others one that saw both inputs, bit for bit (exact arithmetic)."""
+    ch, frames = 2, 300000
+    status, plan = support.oracle_plan(44100, 48000, ch, 4, 64, PUSH, support.GOOD)
+    config = drbamd.make_config(44100, 48000, ch, 4, 64, PUSH, support.GOOD, streams=4)
+    batch = drbamd.Batch(config)
+    hip_streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    first = np.stack([support.white_noise(ch, frames, 270 + s) for s in range(4)])
+    second = np.stack([support.white_noise(ch, frames, 280 + s) for s in range(4)])
+    sources = [torch.from_numpy(first).cuda(), torch.from_numpy(second).cuda()]
+    capacity = batch.query([frames] * 4)[0] + 64
+    targets = [torch.zeros((4, ch, capacity), device="cuda:0") for _ in range(2)]
+    torch.cuda.synchronize()
+    made = []
+    for i in range(2):
+        counts = (drbamd.ctypes.c_int * 4)()
+        batch.process_dense(sources[i].data_ptr(), ch * frames, frames, targets[i].data_ptr(), ch * capacity, capacity,
+                            frames, capacity, stream=hip_streams[i].cuda_stream, produced=counts)
+        made.append(list(counts))
+        if i == 0:
+            batch.reset(1, 2)      # streams 1 and 2 start over, the step above still running
+    for stream in hip_streams:
+        batch.synchronize(stream.cuda_stream)
+    got = targets[1].cpu().numpy()
+    for s in range(4):
+        if s in (1, 2):
+            want = support.oracle_push(plan, second[s])
+        else:
+            both = support.oracle_push(plan, np.concatenate([first[s], second[s]], axis=1))
+            want = both[:, made[0][s]:]
+        assert made[1][s] == want.shape[1], (s, made[1][s], want.shape)
+        assert np.array_equal(got[s, :, :made[1][s]].view(np.uint32), want.view(np.uint32)), s
+    batch.close()
+
+
+def test_host_times_count_waiting_apart_from_work():
+    """drb_amd_host_times: what the host spent inside the process calls, with the time
+    it waited for one of a batch's step slots (the device's time) in a bucket of
+    its own; starting over clears it."""
+    drbamd.host_times(start_over=True)
+    config = drbamd.make_config(44100, 48000, 2, 256, 16, PUSH, support.GOOD, arithmetic=drbamd.FAST, streams=64)
+    batch = drbamd.Batch(config)
+    frames = 44100 * 2 // 256 * 256
+    source = torch.rand((64, 2, frames), device="cuda:0") * 2 - 1
+    capacity = batch.query([frames] * 64)[0] + 4096
+    target = torch.zeros((64, 2, capacity), device="cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(12):        # more steps than the ring has slots: some of them wait
+        batch.process_dense(source.data_ptr(), 2 * frames, frames, target.data_ptr(), 2 * capacity, capacity,
+                            frames, capacity, stream=stream)
+        batch.reset()
+    batch.synchronize(stream)
+    steps, spent = drbamd.host_times()
+    assert steps == 12 and len(spent) == 5
+    assert all(value >= 0.0 for value in spent) and sum(spent[:4]) > 0.0
+    assert sum(spent[:4]) < 12 * 5000.0          # (the host's own work: far below 5 ms a step)
+    assert drbamd.host_times(start_over=True)[0] == 12
+    assert drbamd.host_times() == (0, [0.0] * 5)
+    batch.close()
+
+
 def test_a_device_that_is_not_there_is_refused():
     count = torch.cuda.device_count()
     config = drbamd.make_config(44100, 48000, 2, 4, 64, PUSH, support.GOOD, streams=1, device=count)
