@@ -109,3 +109,43 @@ def test_callback_timestamps_match_upstream(harness):
         assert result[1].tolist() == row["counts"], name
         assert [float(v).hex() for v in harness.stamps] == row["stamps"], name
     assert ran >= 5
+
+
+def test_converters_that_are_never_released_do_not_run_into_the_mapping_limit():
+    """Upstream has no destructor, so a program written against its API never releases a
+    converter; this library keeps each one's device state until the process ends.
+    Every pinned host allocation is a memory mapping, of which a process has about
+    65 000: with nine of them per converter construction failed ("out of memory",
+    on an all but empty GPU) at converter 7 272.  9 000 converters are
+    constructed here in blocks of their own with none released in between; then
+    all are released."""
+    import ctypes
+
+    lib = drbamd.lib
+
+    class Callback(ctypes.Structure):
+        _fields_ = [("process", ctypes.c_void_p), ("state", ctypes.c_void_p)]
+
+    lib.drb_audio_converter_alignment_and_size.argtypes = [ctypes.c_int] * 7 + [ctypes.POINTER(ctypes.c_long)] * 2
+    lib.drb_audio_converter_alignment_and_size.restype = ctypes.c_bool
+    lib.drb_audio_converter_construct.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 7 + [Callback]
+    lib.drb_audio_converter_construct.restype = ctypes.c_void_p
+    lib.drb_amd_converter_release.argtypes = [ctypes.c_void_p]
+    lib.drb_amd_converter_release.restype = None
+
+    request = (44100, 48000, 2, 256, 16, PUSH, support.GOOD)
+    alignment, size = ctypes.c_long(), ctypes.c_long()
+    assert lib.drb_audio_converter_alignment_and_size(*request, ctypes.byref(alignment), ctypes.byref(size))
+    count, each = 9000, (size.value + 63) // 64 * 64
+    arena = ctypes.create_string_buffer(count * each + 64)
+    base = (ctypes.addressof(arena) + 63) // 64 * 64
+    converters = []
+    try:
+        for i in range(count):
+            converter = lib.drb_audio_converter_construct(base + i * each, *request, Callback(None, None))
+            assert converter, "converter %d: %s" % (i + 1, drbamd.lib.drb_amd_last_error().decode())
+            converters.append(converter)
+    finally:
+        for converter in converters:
+            lib.drb_amd_converter_release(converter)
+    assert len(converters) == count
