@@ -66,6 +66,8 @@ typedef struct Fast_Launch
     int halves;                       /* 1: a decimator on its own (target = source / 2)          */
     int doubles;                      /* 1: an interpolator on its own                            */
     int has_sinc;
+    int converts;                     /* 1: changes the buffer format only (the caller's <-> planar float32), frame for frame:
+                                         fast.sample_type / layout -> fast.target_sample_type / target_layout */
     double rate_ratio;                /* this launch's target rate over the chain's               */
     float * history [2];              /* device, launches behind the first                        */
     float * output;                   /* device, planar float32 [stream][channel][output_frames]  */
@@ -300,6 +302,11 @@ static DrbAmd_Status resolve (DrbAmd_Batch_Config const * config, Drb_Plan * pla
  * up-sampler or the first down-sampler).  Returns the number of launches, 0 if
  * some launch has no kernel (fast arithmetic then runs the cascade kernel). */
 static int make_launches (DrbAmd_Batch_Config const * config, Drb_Plan const * plan, int const * first, int const * last, int count, Fast_Launch * launches);
+static int partition_launches
+    (
+        DrbAmd_Batch_Config const * config, Drb_Plan const * plan, int sinc,
+        int const * first, int const * last, int count, Fast_Launch * launches
+    );
 
 /* why the last build_launches on this thread found no matrix-core launches ("" where it found them) */
 static _Thread_local char launches_why [96];
@@ -368,6 +375,78 @@ static int build_launches (DrbAmd_Batch_Config const * config, Drb_Plan const * 
 
     if (count < 1 || count > max_launches) return no_launches("%d launches", count);
 
+    int const made = partition_launches(config, plan, sinc, first, last, count, launches);
+
+    if (made > 0) return made;
+
+    /* The caller's buffer format is what no kernel of the first or the last launch takes
+     * (interleaved buffers of more than two channels, 16-bit samples where a launch
+     * keeps planar float32 on its other side, ...): the launches that planar float32
+     * gets, with one in front that turns the caller's source into planar float32
+     * and one behind that turns the result into the caller's format.  Two more
+     * passes over the samples, and still several times faster than the exact
+     * kernels. */
+    int const plain = config->sample_type == drb_amd_sample_f32 && (config->layout == drb_amd_layout_planar || config->channel_count == 1);
+
+    if (plain || config->channel_count > 8) return 0;
+
+    char why [sizeof(launches_why)];
+
+    memcpy(why, launches_why, sizeof(why));
+
+    DrbAmd_Batch_Config between = *config;
+
+    between.sample_type = drb_amd_sample_f32;
+    between.layout = drb_amd_layout_planar;
+
+    Fast_Launch * const inner = counted_calloc(max_launches, sizeof(Fast_Launch));
+
+    if (!inner) return no_launches("out of host memory");
+
+    int const inside = partition_launches(&between, plan, sinc, first, last, count, inner);
+
+    if (inside <= 0 || inside + 2 > max_launches)
+    {
+        counted_free(inner);
+        memcpy(launches_why, why, sizeof(why));   /* (what kept the caller's own format out says more) */
+
+        return 0;
+    }
+
+    memset(&launches[0], 0, sizeof(launches[0]));
+    memset(&launches[inside + 1], 0, sizeof(launches[0]));
+    memcpy(&launches[1], inner, (size_t)inside * sizeof(Fast_Launch));
+    counted_free(inner);
+
+    Fast_Launch * const in = &launches[0], * const out = &launches[inside + 1];
+
+    in->converts = out->converts = 1;
+    in->rate_ratio = (double)plan->source_rate / (double)plan->target_rate;
+    out->rate_ratio = 1.0;
+    in->fast.usable = out->fast.usable = 1;
+    in->fast.channels = out->fast.channels = config->channel_count;
+    in->fast.sample_type = (int)config->sample_type;
+    in->fast.layout = (int)config->layout;
+    in->fast.target_sample_type = (int)drb_amd_sample_f32;
+    in->fast.target_layout = (int)drb_amd_layout_planar;
+    out->fast.sample_type = (int)drb_amd_sample_f32;
+    out->fast.layout = (int)drb_amd_layout_planar;
+    out->fast.target_sample_type = (int)config->sample_type;
+    out->fast.target_layout = (int)config->layout;
+    launches_why[0] = 0;
+
+    return inside + 2;
+}
+
+/* The launches of the partition first[i] .. last[i] of the plan's stages, or, where
+ * that serves, of the partition with the interpolators in front of the sinc stage's
+ * launch folded into it.  0: some launch has no kernel (launches_why says which). */
+static int partition_launches
+    (
+        DrbAmd_Batch_Config const * config, Drb_Plan const * plan, int sinc,
+        int const * first, int const * last, int count, Fast_Launch * launches
+    )
+{
     /* Interpolators in front of the sinc stage's launch: folded into its filter where
      * the split kernel takes the longer chain (the rates in between then never
      * reach memory), else launches of their own. */
@@ -515,6 +594,8 @@ static double issued_flops (Fast_Launch const * launches, int count, double * ha
     {
         Drb_Fast_Chain const * const fast = &launches[i].fast;
 
+        if (launches[i].converts) continue;
+
         /* 16 x 16 x 4 products of 2048 flop each, per tile of one channel */
         long const up_blocks = fast->has_up ? (fast->seg_x + 15) / 16 : 0;
         long const down_blocks = fast->has_down ? (fast->seg_y + 15) / 16 : 0;
@@ -580,7 +661,10 @@ DrbAmd_Status drb_amd_plan_info (DrbAmd_Batch_Config const * config, DrbAmd_Plan
 
     info->fast_path = count > 0;
     info->fast_launches = count;
-    info->fast_tile_frames = count > 0 ? launches[count - 1].fast.tile_frames : 0;
+    info->fast_tile_frames = 0;
+
+    for (int i = 0; i < count; i++) if (!launches[i].converts) info->fast_tile_frames = launches[i].fast.tile_frames;   /* (of the last launch that filters) */
+
     info->fast_issued_flops_per_output_sample = issued_flops(launches, count, &info->fast_issued_half_flops_per_output_sample);
 
     for (int i = 0; i < count; i++) if (launches[i].fast.kind >= 3) info->fast_collapsed = launches[i].fast.kind - 2;
@@ -589,11 +673,13 @@ DrbAmd_Status drb_amd_plan_info (DrbAmd_Batch_Config const * config, DrbAmd_Plan
     {
         char const * name = "drb_cascade_kernel";
 
-        for (int i = 0; i < count; i++)
+        for (int i = 0, seen = 0; i < count; i++)
         {
             int const kind = launches[i].fast.kind;
 
-            if (i == 0 || launches[i].has_sinc)
+            if (launches[i].converts) continue;
+
+            if (!seen++ || launches[i].has_sinc)
             {
                 name = kind == 4 ? "drb_split_kernel" : kind == 2 ? "drb_interpolate_kernel"
                      : kind == 1 ? "drb_decimate_kernel" : "drb_fast_kernel";
@@ -823,6 +909,45 @@ DrbAmd_Status drb_amd_batch_create (DrbAmd_Batch_Config const * config, DrbAmd_B
     if (!code) code = drb_hip_alloc((void **)&batch->calls_device, n * max_launches * sizeof(Drb_Device_Call));
     if (!code) code = drb_hip_alloc((void **)&batch->fault_device, fault_words * sizeof(long long));
 
+    /* The buffers between a chain's launches, for steps of up to 16 384 frames on the
+     * caller's side (or what fits half a gigabyte): they grow with the steps that come,
+     * but a call that may not allocate finds these from the first step on. */
+    if (!code && batch->launch_count > 1)
+    {
+        enum { modest_step = 16384 };
+        size_t const budget = ((size_t)512 << 20) / (size_t)(batch->launch_count - 1);
+        int const last_filter = batch->launch_count - 1 - (batch->launches[batch->launch_count - 1].converts ? 1 : 0);
+        Drb_Stream_State trial;
+        Drb_Step step;
+
+        drb_stream_reset(&plan, &trial);
+
+        if (drb_stream_step(&plan, &trial, modest_step, &step))
+        {
+            long long frames = step.source_frames;
+
+            for (int l = 0; l + 1 < batch->launch_count && !code; l++)
+            {
+                Fast_Launch * const launch = &batch->launches[l];
+
+                /* (the rule of drb_amd_batch_process for the frames between launches) */
+                frames = l >= last_filter ? step.target_frames
+                       : launch->converts ? frames
+                       : launch->doubles ? 2 * frames
+                       : (long long)step.target_frames << launch->downs_behind;
+
+                long long room = (frames + frames / 4 + 255) / 256 * 256;
+                size_t const each = n * plan.channels * sizeof(float);
+
+                if ((size_t)room * each > budget) room = (long long)(budget / each) / 256 * 256;
+                if (room < 1024) continue;   /* (very many streams: left to the first step) */
+
+                code = drb_hip_alloc((void **)&launch->output, (size_t)room * each);
+                if (!code) launch->output_frames = room;
+            }
+        }
+    }
+
     /* pinned: the fault word, then per ring slot the step descriptors, then per ring slot
      * the tables every step of a modest size fits (a call that may not allocate
      * finds them there) */
@@ -850,6 +975,8 @@ DrbAmd_Status drb_amd_batch_create (DrbAmd_Batch_Config const * config, DrbAmd_B
 
     for (int i = 1; i < batch->launch_count && !code; i++)
     {
+        if (batch->launches[i].converts) continue;   /* (frame for frame: nothing to remember) */
+
         size_t const bytes = n * plan.channels * (size_t)batch->launches[i].chain.history * sizeof(float);
 
         code = drb_hip_alloc((void **)&batch->launches[i].history[0], bytes);
@@ -959,6 +1086,8 @@ DrbAmd_Status drb_amd_batch_reset (DrbAmd_Batch * batch, int first, int count)
 
         for (int l = 1; l < batch->launch_count && !code; l++)
         {
+            if (batch->launches[l].converts) continue;
+
             size_t const each = (size_t)batch->plan.channels * batch->launches[l].chain.history * sizeof(float);
 
             for (int i = 0; i < 2 && !code; i++)
@@ -1296,6 +1425,10 @@ DrbAmd_Status drb_amd_batch_process
     /* frames between the launches: an interpolator on its own doubles what it
      * gets; everything from the sinc stage on is counted back from the target */
     long long least [max_launches];  /* and fewest */
+    /* the last launch that filters makes the step's target frames (a slicer behind it may hold
+     * frames back or hand out held ones: not "twice what came in"); a launch behind it only
+     * changes their format */
+    int const last_filter = launches - 1 - (fast && launches > 1 && batch->launches[launches - 1].converts ? 1 : 0);
 
     for (int l = 0; l < launches; l++) { most[l] = 0; least[l] = 0x7fffffffffffffffLL; }
 
@@ -1307,7 +1440,8 @@ DrbAmd_Status drb_amd_batch_process
         {
             Fast_Launch const * const launch = &batch->launches[l];
 
-            frames = l == launches - 1 ? batch->steps[s].target_frames
+            frames = l >= last_filter ? batch->steps[s].target_frames
+                   : launch->converts ? frames
                    : launch->doubles ? 2 * frames
                    : (long long)batch->steps[s].target_frames << launch->downs_behind;
 
@@ -1352,7 +1486,8 @@ DrbAmd_Status drb_amd_batch_process
             Fast_Launch const * const launch = &batch->launches[l];
             Fast_Launch const * const before = l > 0 ? &batch->launches[l - 1] : 0;
             Drb_Device_Call * const call = &calls[(size_t)l * n + s];
-            long long const out = l == launches - 1 ? step->target_frames
+            long long const out = l >= last_filter ? step->target_frames
+                                : launch->converts ? frames
                                 : launch->doubles ? 2 * frames
                                 : (long long)step->target_frames << launch->downs_behind;
 
@@ -1479,7 +1614,16 @@ DrbAmd_Status drb_amd_batch_process
             long long const target_stride = l == launches - 1 ? target_channel_stride : launch->output_frames;
             int const fast_tile = shape->tile_frames;
 
-            if (shape->kind >= 3)
+            if (launch->converts)
+            {
+                code = drb_hip_launch_convert
+                (
+                    launch_calls, n, most[l], batch->plan.channels,
+                    shape->sample_type, shape->layout, source_stride,
+                    shape->target_sample_type, shape->target_layout, target_stride, hip_stream
+                );
+            }
+            else if (shape->kind >= 3)
             {
                 /* (several groups: a group's sets are built where the last group's were, behind its filter kernel) */
                 for (int g = 0; g < batch->group_count && !code; g++)
@@ -1513,7 +1657,7 @@ DrbAmd_Status drb_amd_batch_process
             );
 
             /* what this launch read becomes the history of its next step */
-            if (!code && l > 0)
+            if (!code && l > 0 && !launch->converts)
             {
                 code = drb_hip_launch_history
                 (

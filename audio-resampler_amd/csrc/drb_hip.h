@@ -244,6 +244,13 @@ int drb_hip_launch_collapsed
 
 /* Writes every stream's new look-back (the last `history` source frames seen
  * so far) into history_out. */
+/* a launch that only changes the buffer format of every stream's step (calls: its source and target, frames = target_frames) */
+int drb_hip_launch_convert
+    (
+        Drb_Device_Call const * calls, int stream_count, long long most_frames, int channels,
+        int source_type, int source_layout, long long source_channel_stride,
+        int target_type, int target_layout, long long target_channel_stride, void * stream
+    );
 int drb_hip_launch_history
     (
         Drb_Device_Chain const * chain,

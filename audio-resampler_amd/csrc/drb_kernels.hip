@@ -693,6 +693,81 @@ static std::mutex scratch_lock;
 
 // ---- C ABI --------------------------------------------------------------------
 
+// ---- a launch that only changes the buffer format ------------------------------------------
+// Fast arithmetic runs longer chains as several launches with planar float32 between
+// them.  Where the first (last) launch's kernel cannot take the caller's buffer
+// format, this one stands in front of (behind) it: every sample through
+// load_sample / store_sample, the conversions of the exact path, by way of a tile
+// in LDS so that both sides are accessed along their own layout.
+constexpr int kConvertFrames = 256, kConvertTiles = 4, kConvertChannels = 8;
+
+__global__ __launch_bounds__(256) void drb_convert_kernel
+    (
+        Drb_Device_Call const * __restrict__ calls, int channels,
+        int source_type, int source_layout, long long source_channel_stride,
+        int target_type, int target_layout, long long target_channel_stride
+    )
+{
+    __shared__ float tile [kConvertChannels][kConvertFrames + 1];
+
+    Drb_Device_Call const call = calls[blockIdx.x];   // (streams along x: there may be more of them than y takes)
+    int const frames = call.target_frames;
+    void const * const source = reinterpret_cast<void const *>(call.source);
+    void * const target = reinterpret_cast<void *>(call.target);
+
+    for (int t = 0; t < kConvertTiles; t++)
+    {
+        int const first = (blockIdx.y * kConvertTiles + t) * kConvertFrames;
+        int const count = min(kConvertFrames, frames - first);
+
+        if (count <= 0) return;   // (the same for every thread of the workgroup)
+
+        if (source_layout == kInterleaved)
+        {
+            for (int i = threadIdx.x; i < count * channels; i += blockDim.x)
+            {
+                int const frame = i / channels, c = i - frame * channels;
+
+                tile[c][frame] = load_sample(source, static_cast<long long>(first) * channels + i, source_type);
+            }
+        }
+        else
+        {
+            for (int c = 0; c < channels; c++)
+            {
+                for (int frame = threadIdx.x; frame < count; frame += blockDim.x)
+                {
+                    tile[c][frame] = load_sample(source, c * source_channel_stride + first + frame, source_type);
+                }
+            }
+        }
+
+        __syncthreads();
+
+        if (target_layout == kInterleaved)
+        {
+            for (int i = threadIdx.x; i < count * channels; i += blockDim.x)
+            {
+                int const frame = i / channels, c = i - frame * channels;
+
+                store_sample(target, static_cast<long long>(first) * channels + i, target_type, tile[c][frame]);
+            }
+        }
+        else
+        {
+            for (int c = 0; c < channels; c++)
+            {
+                for (int frame = threadIdx.x; frame < count; frame += blockDim.x)
+                {
+                    store_sample(target, c * target_channel_stride + first + frame, target_type, tile[c][frame]);
+                }
+            }
+        }
+
+        __syncthreads();
+    }
+}
+
 extern "C" {
 
 // The calling thread's current device must be `device`.
@@ -968,6 +1043,29 @@ int drb_hip_launch_cascade
     (
         *chain, calls, stream_count, history,
         source_channel_stride, target_channel_stride, bank_floats, fault_flag
+    );
+
+    return hipGetLastError();
+}
+
+int drb_hip_launch_convert
+    (
+        Drb_Device_Call const * calls, int stream_count, long long most_frames, int channels,
+        int source_type, int source_layout, long long source_channel_stride,
+        int target_type, int target_layout, long long target_channel_stride, void * stream
+    )
+{
+    if (stream_count <= 0 || most_frames <= 0) return 0;
+    if (channels < 1 || channels > kConvertChannels) return hipErrorInvalidValue;
+
+    long long const each = static_cast<long long>(kConvertFrames) * kConvertTiles;
+    long long const blocks = (most_frames + each - 1) / each;
+
+    if (blocks > 65535) return hipErrorInvalidValue;   // (a step has at most 2^24 frames: 16 384 blocks)
+
+    drb_convert_kernel<<<dim3(static_cast<unsigned>(stream_count), static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream)>>>
+    (
+        calls, channels, source_type, source_layout, source_channel_stride, target_type, target_layout, target_channel_stride
     );
 
     return hipGetLastError();

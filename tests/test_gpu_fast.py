@@ -574,14 +574,13 @@ def test_fast_mode_first_launch_reads_the_callers_format(src, dst, quality, samp
     three_streams_against_the_oracle(src, dst, quality, sample, layout, direction, launches=launches)
 
 
-def three_streams_against_the_oracle(src, dst, quality, sample, layout, direction, launches):
-    ch = 2
+def three_streams_against_the_oracle(src, dst, quality, sample, layout, direction, launches, ch=2, collapsed=2):
     sample_type = {"f32": drbamd.F32, "i16": drbamd.I16}[sample]
     layout_type = drbamd.INTERLEAVED if layout == "interleaved" else drbamd.PLANAR
     config = drbamd.make_config(src, dst, ch, 256, 16, direction, quality, sample_type=sample_type, layout=layout_type,
                                 arithmetic=drbamd.FAST, streams=3)
     info = drbamd.plan_info(config)
-    assert info.fast_path == 1 and info.fast_collapsed == 2 and info.fast_launches == launches, (info.fast_launches, info.fast_why_not)
+    assert info.fast_path == 1 and info.fast_collapsed == collapsed and info.fast_launches == launches, (info.fast_launches, info.fast_why_not)
     status, plan = support.oracle_plan(src, dst, ch, 256, 16, direction, quality)
     assert status == 1
     user_rate = dst if direction == PULL else src
@@ -611,3 +610,29 @@ def three_streams_against_the_oracle(src, dst, quality, sample, layout, directio
         else:
             assert_close(got, want, "stream %d" % s)
     runner.close()
+
+
+CONVERTED = [
+    # src, dst, channels, quality, sample, layout, direction, launches, split form: the launches that planar
+    # float32 gets, between one that turns the caller's buffers into planar float32 and one that turns the
+    # result back
+    (11025, 48000, 2, support.GOOD, "i16", "interleaved", PUSH, 5, 2),     # three interpolators, then the fractional stage's launch
+    (96000, 48000, 8, support.GOOD, "f32", "interleaved", PUSH, 3, 0),     # cfg3's decimator on interleaved buffers
+    (22050, 96000, 3, support.FINE, "i16", "planar", PUSH, 5, 2),
+    (48000, 11025, 5, support.GOOD, "f32", "interleaved", PULL, 3, 0),
+    (88200, 44100, 6, support.BEST, "i16", "interleaved", PUSH, 3, 0),
+    (44100, 88200, 4, support.GOOD, "i16", "interleaved", PUSH, 3, 0),
+    (11025, 44100, 7, support.GOOD, "i16", "interleaved", PULL, 4, 0),
+]
+
+
+@pytest.mark.parametrize("src,dst,ch,quality,sample,layout,direction,launches,collapsed", CONVERTED)
+def test_fast_mode_buffer_formats_no_kernel_takes_go_through_planar_float32(src, dst, ch, quality, sample, layout, direction,
+                                                                              launches, collapsed):
+    """Interleaved buffers of more than two channels, and 16-bit or interleaved buffers at
+    the ends of chains whose first or last launch keeps planar float32 on both sides,
+    ran the exact kernels in fast arithmetic.  Now a launch that only converts (the
+    exact path's sample conversions, frame for frame) stands in front of the chain
+    and one behind it.  Three streams in calls of uneven length against the upstream
+    converter's restatement; 16-bit results within one step."""
+    three_streams_against_the_oracle(src, dst, quality, sample, layout, direction, launches=launches, ch=ch, collapsed=collapsed)

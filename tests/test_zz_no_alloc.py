@@ -76,6 +76,71 @@ def test_static_entry_point_matches_the_regular_one(case):
     static.close()
 
 
+CHAINS = [
+    ("three launches going down, planar float32", 48000, 16000, 2, support.GOOD, False, 3),
+    ("a decimator between two launches that convert, 8 channels interleaved", 96000, 48000, 8, support.GOOD, True, 3),
+    ("three launches going up between two that convert, 3 channels interleaved", 11025, 48000, 3, support.FINE, True, 5),
+]
+
+
+@pytest.mark.parametrize("case", CHAINS, ids=[c[0] for c in CHAINS])
+def test_static_entry_point_on_chains_of_several_launches_from_the_first_call(case):
+    """A chain of several launches keeps planar float32 buffers between them, which grow with
+    the steps.  A batch has them from its creation for steps of up to 16 384 frames, so
+    that the entry point that may not allocate serves such a chain from its first
+    call on: two calls of 8192 and 4096 frames on a fresh batch, bit for bit what
+    the regular entry point makes, with nothing allocated."""
+    _, src, dst, ch, quality, interleaved, launches = case
+    streams = 3
+    config = drbamd.make_config(src, dst, ch, 256, 16, PUSH, quality, arithmetic=drbamd.FAST, streams=streams,
+                                layout=drbamd.INTERLEAVED if interleaved else drbamd.PLANAR)
+    assert drbamd.plan_info(config).fast_launches == launches
+    regular, static = drbamd.Batch(config), drbamd.Batch(config)
+    calls = [8192, 4096]
+    total = sum(calls)
+    x = np.stack([support.white_noise(ch, total, 520 + s) for s in range(streams)])       # [stream][channel][frame]
+    host = np.ascontiguousarray(x.transpose(0, 2, 1)) if interleaved else x
+    source = torch.from_numpy(host).cuda()
+    capacity = regular.query([total] * streams)[0] + 4096
+    shape = (streams, capacity, ch) if interleaved else (streams, ch, capacity)
+    outputs = [torch.zeros(shape, device="cuda:0") for _ in range(2)]
+    stream = torch.cuda.current_stream().cuda_stream
+    frame_bytes = 4 * ch if interleaved else 4
+    source_strides = (total * ch, 0 if interleaved else total)
+    target_strides = (capacity * ch, 0 if interleaved else capacity)
+    made, at = [0, 0], 0
+    for frames in calls:
+        for which, (batch, entry) in enumerate(((regular, regular.process_dense), (static, static.process_dense_static))):
+            counts = (ctypes.c_int * streams)()
+            torch.cuda.synchronize()
+            free_before = torch.cuda.mem_get_info()[0]
+            calls_before = drbamd.lib.drb_amd_allocation_calls()
+            entry(source.data_ptr() + frame_bytes * at, *source_strides,
+                  outputs[which].data_ptr() + frame_bytes * made[which], *target_strides,
+                  frames, capacity - made[which], stream=stream, produced=counts)
+            calls_after = drbamd.lib.drb_amd_allocation_calls()
+            torch.cuda.synchronize()
+            if which == 1:
+                assert torch.cuda.mem_get_info()[0] == free_before, "device memory allocated by the static entry point"
+                assert calls_after == calls_before, "the static entry point allocated or freed something"
+            assert len(set(counts)) == 1
+            made[which] += counts[0]
+        at += frames
+    regular.synchronize(stream)
+    static.synchronize(stream)
+    assert made[0] == made[1] > 0
+    want, got = outputs[0].cpu().numpy(), outputs[1].cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    status, plan = support.oracle_plan(src, dst, ch, 256, 16, PUSH, quality)
+    for s in range(streams):
+        upstream = support.oracle_push(plan, x[s])
+        mine = got[s, :made[1], :].T if interleaved else got[s, :, :made[1]]
+        assert mine.shape == upstream.shape
+        assert np.abs(mine.astype(np.float64) - upstream).max() <= 1e-6 + 1e-5 * np.abs(upstream).max()
+    regular.close()
+    static.close()
+
+
 def test_static_entry_point_rejects_what_does_not_fit():
     """More step descriptors than the workspace holds: a clear error, nothing enqueued."""
     streams = 30000
