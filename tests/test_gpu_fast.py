@@ -615,14 +615,14 @@ def three_streams_against_the_oracle(src, dst, quality, sample, layout, directio
 CONVERTED = [
     # src, dst, channels, quality, sample, layout, direction, launches, split form: the launches that planar
     # float32 gets, between one that turns the caller's buffers into planar float32 and one that turns the
-    # result back
+    # result back (chains of 150 flop per target sample and more: cheaper ones stay on the exact kernels)
     (11025, 48000, 2, support.GOOD, "i16", "interleaved", PUSH, 5, 2),     # three interpolators, then the fractional stage's launch
-    (96000, 48000, 8, support.GOOD, "f32", "interleaved", PUSH, 3, 0),     # cfg3's decimator on interleaved buffers
     (22050, 96000, 3, support.FINE, "i16", "planar", PUSH, 5, 2),
     (48000, 11025, 5, support.GOOD, "f32", "interleaved", PULL, 3, 0),
-    (88200, 44100, 6, support.BEST, "i16", "interleaved", PUSH, 3, 0),
-    (44100, 88200, 4, support.GOOD, "i16", "interleaved", PUSH, 3, 0),
-    (11025, 44100, 7, support.GOOD, "i16", "interleaved", PULL, 4, 0),
+    (176400, 44100, 6, support.GOOD, "i16", "interleaved", PUSH, 4, 0),    # two decimators
+    (192000, 48000, 8, support.BEST, "f32", "interleaved", PUSH, 4, 0),
+    (176400, 22050, 5, support.GOOD, "i16", "interleaved", PULL, 5, 0),    # pull, a slicer in front of three decimators
+    (176400, 22050, 7, support.BEST, "i16", "interleaved", PULL, 5, 0),
 ]
 
 
@@ -636,3 +636,15 @@ def test_fast_mode_buffer_formats_no_kernel_takes_go_through_planar_float32(src,
     and one behind it.  Three streams in calls of uneven length against the upstream
     converter's restatement; 16-bit results within one step."""
     three_streams_against_the_oracle(src, dst, quality, sample, layout, direction, launches=launches, ch=ch, collapsed=collapsed)
+
+
+def test_cheap_chains_keep_the_exact_kernels_where_two_more_passes_would_not_pay():
+    """One decimator or a few interpolators cost the exact kernels less than a pass over
+    the samples costs the memory: on buffers no kernel of theirs takes, such chains
+    stay there (measured 5 to 47 % faster than through planar float32), and the plan
+    says so."""
+    for src, dst, ch, quality in ((96000, 48000, 8, support.GOOD), (44100, 88200, 4, support.GOOD), (11025, 44100, 7, support.GOOD)):
+        config = drbamd.make_config(src, dst, ch, 256, 16, PUSH, quality, sample_type=drbamd.I16, layout=drbamd.INTERLEAVED,
+                                    arithmetic=drbamd.FAST, streams=2)
+        info = drbamd.plan_info(config)
+        assert info.fast_path == 0 and b"would not pay" in info.fast_why_not, (src, dst, info.fast_why_not)

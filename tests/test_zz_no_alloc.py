@@ -78,7 +78,7 @@ def test_static_entry_point_matches_the_regular_one(case):
 
 CHAINS = [
     ("three launches going down, planar float32", 48000, 16000, 2, support.GOOD, False, 3),
-    ("a decimator between two launches that convert, 8 channels interleaved", 96000, 48000, 8, support.GOOD, True, 3),
+    ("two decimators between two launches that convert, 8 channels interleaved", 192000, 48000, 8, support.BEST, True, 4),
     ("three launches going up between two that convert, 3 channels interleaved", 11025, 48000, 3, support.FINE, True, 5),
 ]
 
