@@ -238,6 +238,21 @@ static void build_chain (DrbAmd_Batch_Config const * config, Drb_Plan const * pl
     chain->target_delta = plan->target_delta > 0 ? plan->target_delta : 1;
     chain->scale = 1.0 / (double)chain->source_delta; /* drb-audio-converter.c:1767 */
 
+    /* the fractional stage's rates back from the deltas (2^48 / rate, rounded down), and
+     * the period of their ratio in output frames */
+    if (plan->source_delta > 0 && plan->target_delta > 0)
+    {
+        long long const in_rate = llround(0x1.0p48 / (double)plan->source_delta);
+        long long const out_rate = llround(0x1.0p48 / (double)plan->target_delta);
+        long long a = in_rate, b = out_rate;
+
+        while (b > 0) { long long const r = a % b; a = b; b = r; }
+
+        long long const period = a > 0 ? out_rate / a : 0;
+
+        chain->sinc_period = period >= 1 && period <= 2048 ? (int)period : 0;
+    }
+
     for (int k = 0; k < plan->stage_count; k++)
     {
         Drb_Stage const * const stage = &plan->stages[k];
@@ -257,7 +272,7 @@ static void build_chain (DrbAmd_Batch_Config const * config, Drb_Plan const * pl
     }
 }
 
-enum { lds_budget = 56 * 1024, fast_lds_budget = 78 * 1024, split_lds_budget = 160 * 1024 };
+enum { lds_budget = 53500, fast_lds_budget = 78 * 1024, split_lds_budget = 160 * 1024 };
 
 static DrbAmd_Status resolve (DrbAmd_Batch_Config const * config, Drb_Plan * plan)
 {

@@ -37,6 +37,11 @@ typedef struct Drb_Device_Chain
     long long source_delta;  /* 2^48 / fractional stage input rate               */
     long long target_delta;  /* 2^48 / fractional stage output rate              */
     double scale;            /* 1.0 / source_delta                               */
+    int sinc_period;         /* fractional stage outputs after which its position
+                                recurs (but for the fixed-point drift); 0: unknown */
+    int ablate;              /* diagnostic: bit mask of phases to skip (timing only):
+                                1 fractional stage, 2 up-samplers, 4 down-samplers,
+                                8 source loads, 16 target stores                  */
     Drb_Device_Stage stages [drb_device_max_stages];
 }
 Drb_Device_Chain;

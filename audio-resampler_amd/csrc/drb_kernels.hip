@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <cstdlib>
 #include <mutex>
 
 #include "drb_hip.h"
@@ -303,6 +304,153 @@ __device__ void stage_down2x
 // so that lanes reading different rows at the same tap hit different banks.
 // Row pick and blend: drb-audio-converter.c:881-941; linear blend 827-848;
 // Catmull-Rom 850-875.
+
+// where output `index` of the stage reads: its bank row, the position inside the row's
+// interval and the first input position (relative to the edge buffer's origin)
+template <int TAPS, int CUBIC>
+__device__ __forceinline__ void sinc_frame
+    (
+        Drb_Device_Chain const & chain, long long phase_base, int index, int in_origin,
+        int & row, float & sub, int & start
+    )
+{
+    int consumed;
+    double blend;
+
+    sinc_position
+    (
+        phase_base + static_cast<long long>(index) * chain.target_delta,
+        chain.source_delta, chain.scale, chain.sinc_pull, consumed, blend
+    );
+
+    double const scaled = blend * (CUBIC ? 29.0 : 63.0);
+
+    row = static_cast<int>(scaled);
+    sub = static_cast<float>(scaled - static_cast<double>(row));
+    start = consumed - TAPS - in_origin;
+}
+
+// the rows' sums of one frame and channel pair into the frame's two samples
+template <int CUBIC>
+__device__ __forceinline__ void sinc_blend (float2_t const * p, float sub, float & ya, float & yb)
+{
+    constexpr int kRows = CUBIC ? 4 : 2;
+    float pa [kRows], pb [kRows];
+
+    #pragma unroll
+    for (int r = 0; r < kRows; r++) { pa[r] = p[r][0]; pb[r] = p[r][1]; }
+
+    if (CUBIC)
+    {
+        // a_i = sum_j M[i][j] p[j], accumulated from zero in order
+        float const m [4][4] =
+        {
+            {  0.0f,  1.0f,  0.0f,  0.0f },
+            { -0.5f,  0.0f,  0.5f,  0.0f },
+            {  1.0f, -2.5f,  2.0f, -0.5f },
+            { -0.5f,  1.5f, -1.5f,  0.5f }
+        };
+        float ca [4], cb [4];
+
+        #pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            float sa = 0.0f, sb = 0.0f;
+
+            #pragma unroll
+            for (int j = 0; j < 4; j++)
+            {
+                sa = mac(sa, m[i][j], pa[j]);
+                sb = mac(sb, m[i][j], pb[j]);
+            }
+
+            ca[i] = sa;
+            cb[i] = sb;
+        }
+
+        ya = add(mul(add(mul(add(mul(ca[3], sub), ca[2]), sub), ca[1]), sub), ca[0]);
+        yb = add(mul(add(mul(add(mul(cb[3], sub), cb[2]), sub), cb[1]), sub), cb[0]);
+    }
+    else
+    {
+        float const a0 = mac(mac(0.0f, 1.0f, pa[0]), 0.0f, pa[1]);
+        float const a1 = mac(mac(0.0f, -1.0f, pa[0]), 1.0f, pa[1]);
+        float const b0 = mac(mac(0.0f, 1.0f, pb[0]), 0.0f, pb[1]);
+        float const b1 = mac(mac(0.0f, -1.0f, pb[0]), 1.0f, pb[1]);
+
+        ya = add(mul(a1, sub), a0);
+        yb = add(mul(b1, sub), b0);
+    }
+}
+
+// one output frame, all channels
+template <int TAPS, int CUBIC>
+__device__ __forceinline__ void sinc_one
+    (
+        Drb_Device_Chain const & chain, long long phase_base,
+        float const * in, float * out, int width, int channels, int out_split,
+        int first_output, int item, int in_origin, float const * bank
+    )
+{
+    // (p + x * k below must stay a rounded product and a rounded sum, as upstream's)
+    #pragma clang fp contract(off)
+
+    constexpr int kRows = CUBIC ? 4 : 2;
+    constexpr int kStride = TAPS + 1;
+
+    int row, start;
+    float sub;
+
+    sinc_frame<TAPS, CUBIC>(chain, phase_base, first_output + item, in_origin, row, sub, start);
+
+    float const * const rows = bank + row * kStride;
+
+    for (int channel = 0; channel < channels; channel += 2)
+    {
+        bool const pair = channel + 1 < channels;
+        float const * const a = in + channel * width + start;
+        float const * const b = pair ? a + width : a;
+
+        // Two channels side by side in packed registers: one v_pk_mul_f32 and one
+        // v_pk_add_f32 per tap and row, each half rounded as the scalar
+        // instructions round, in the same order.
+        float2_t p [kRows];
+
+        #pragma unroll
+        for (int r = 0; r < kRows; r++) p[r] = float2_t{ 0.0f, 0.0f };
+
+        #pragma unroll
+        for (int t = 0; t < TAPS; t++)
+        {
+            float2_t const x = { a[t], b[t] };
+
+            #pragma unroll
+            for (int r = 0; r < kRows; r++)
+            {
+                float const k = rows[r * kStride + t];
+                p[r] = p[r] + x * float2_t{ k, k };
+            }
+        }
+
+        float ya, yb;
+
+        sinc_blend<CUBIC>(p, sub, ya, yb);
+
+        put(out + channel * width, width, out_split, item, ya);
+        if (pair) put(out + (channel + 1) * width, width, out_split, item, yb);
+    }
+}
+
+// Outputs `period` apart sit at (nearly) the same fractional position: the rate ratio's
+// period, up to the slow drift of the fixed-point phase.  A work item takes kShare such
+// frames (item c of set q: frames c + period (kShare q + m)), and where all of them pick
+// the same bank row, as they do but for a frame in a million, every coefficient is read
+// from LDS once for the kShare frames: the stage is bound by its LDS reads, two thirds
+// of which were coefficients.  Each frame's sums are formed as sinc_one forms them.
+// Frames past the last full set, and any stage with fewer outputs than one set, go frame
+// by frame.
+constexpr int kShare = 2;
+
 template <int TAPS, int CUBIC>
 __device__ void stage_sinc
     (
@@ -311,110 +459,101 @@ __device__ void stage_sinc
         int first_output, int outputs, int in_origin, float const * bank
     )
 {
-    // (p + x * k below must stay a rounded product and a rounded sum, as upstream's)
     #pragma clang fp contract(off)
 
     constexpr int kRows = CUBIC ? 4 : 2;
     constexpr int kStride = TAPS + 1;
-    double const bank_scale = CUBIC ? 29.0 : 63.0;
 
-    for (int item = threadIdx.x; item < outputs; item += kThreads)
+    int const period = chain.sinc_period;
+    int const span = kShare * period;
+    int const sets = period > 0 ? outputs / span : 0;
+
+    for (int item = threadIdx.x; item < sets * period; item += kThreads)
     {
-        int consumed;
-        double blend;
+        int const set = item / period, c = item - set * period;
+        int const first = c + set * span;
 
-        sinc_position
-        (
-            phase_base + static_cast<long long>(first_output + item) * chain.target_delta,
-            chain.source_delta, chain.scale, chain.sinc_pull, consumed, blend
-        );
+        int row [kShare], start [kShare];
+        float sub [kShare];
 
-        double const scaled = blend * bank_scale;
-        int const row = static_cast<int>(scaled);
-        float const sub = static_cast<float>(scaled - static_cast<double>(row));
+        #pragma unroll
+        for (int m = 0; m < kShare; m++)
+        {
+            sinc_frame<TAPS, CUBIC>(chain, phase_base, first_output + first + m * period, in_origin, row[m], sub[m], start[m]);
+        }
 
-        float const * const rows = bank + row * kStride;
-        int const start = consumed - TAPS - in_origin;
+        bool same = true;
+
+        #pragma unroll
+        for (int m = 1; m < kShare; m++) same = same && row[m] == row[0];
+
+        if (!same)
+        {
+            #pragma unroll 1
+            for (int m = 0; m < kShare; m++)
+            {
+                sinc_one<TAPS, CUBIC>(chain, phase_base, in, out, width, channels, out_split, first_output, first + m * period, in_origin, bank);
+            }
+
+            continue;
+        }
+
+        float const * const rows = bank + row[0] * kStride;
 
         for (int channel = 0; channel < channels; channel += 2)
         {
             bool const pair = channel + 1 < channels;
-            float const * const a = in + channel * width + start;
+            float const * const a = in + channel * width;
             float const * const b = pair ? a + width : a;
 
-            // Two channels side by side in packed registers: one v_pk_mul_f32 and one
-            // v_pk_add_f32 per tap and row, each half rounded as the scalar
-            // instructions round, in the same order.
-            float2_t p [kRows];
+            float2_t p [kShare][kRows];
 
             #pragma unroll
-            for (int r = 0; r < kRows; r++) p[r] = float2_t{ 0.0f, 0.0f };
+            for (int m = 0; m < kShare; m++)
+            {
+                #pragma unroll
+                for (int r = 0; r < kRows; r++) p[m][r] = float2_t{ 0.0f, 0.0f };
+            }
 
-            #pragma unroll
+            // (four taps at a time: unrolled further, the compiler starts every read of the
+            // stage at once and runs out of registers)
+            #pragma unroll 4
             for (int t = 0; t < TAPS; t++)
             {
-                float2_t const x = { a[t], b[t] };
+                float k [kRows];
 
                 #pragma unroll
-                for (int r = 0; r < kRows; r++)
-                {
-                    float const k = rows[r * kStride + t];
-                    p[r] = p[r] + x * float2_t{ k, k };
-                }
-            }
-
-            float pa [kRows], pb [kRows];
-
-            #pragma unroll
-            for (int r = 0; r < kRows; r++) { pa[r] = p[r][0]; pb[r] = p[r][1]; }
-
-            float ya, yb;
-
-            if (CUBIC)
-            {
-                // a_i = sum_j M[i][j] p[j], accumulated from zero in order
-                float const m [4][4] =
-                {
-                    {  0.0f,  1.0f,  0.0f,  0.0f },
-                    { -0.5f,  0.0f,  0.5f,  0.0f },
-                    {  1.0f, -2.5f,  2.0f, -0.5f },
-                    { -0.5f,  1.5f, -1.5f,  0.5f }
-                };
-                float ca [4], cb [4];
+                for (int r = 0; r < kRows; r++) k[r] = rows[r * kStride + t];
 
                 #pragma unroll
-                for (int i = 0; i < 4; i++)
+                for (int m = 0; m < kShare; m++)
                 {
-                    float sa = 0.0f, sb = 0.0f;
+                    float2_t const x = { a[start[m] + t], b[start[m] + t] };
 
                     #pragma unroll
-                    for (int j = 0; j < 4; j++)
-                    {
-                        sa = mac(sa, m[i][j], pa[j]);
-                        sb = mac(sb, m[i][j], pb[j]);
-                    }
-
-                    ca[i] = sa;
-                    cb[i] = sb;
+                    for (int r = 0; r < kRows; r++) p[m][r] = p[m][r] + x * float2_t{ k[r], k[r] };
                 }
-
-                ya = add(mul(add(mul(add(mul(ca[3], sub), ca[2]), sub), ca[1]), sub), ca[0]);
-                yb = add(mul(add(mul(add(mul(cb[3], sub), cb[2]), sub), cb[1]), sub), cb[0]);
             }
-            else
+
+            #pragma unroll
+            for (int m = 0; m < kShare; m++)
             {
-                float const a0 = mac(mac(0.0f, 1.0f, pa[0]), 0.0f, pa[1]);
-                float const a1 = mac(mac(0.0f, -1.0f, pa[0]), 1.0f, pa[1]);
-                float const b0 = mac(mac(0.0f, 1.0f, pb[0]), 0.0f, pb[1]);
-                float const b1 = mac(mac(0.0f, -1.0f, pb[0]), 1.0f, pb[1]);
+                float ya, yb;
 
-                ya = add(mul(a1, sub), a0);
-                yb = add(mul(b1, sub), b0);
+                sinc_blend<CUBIC>(p[m], sub[m], ya, yb);
+
+                put(out + channel * width, width, out_split, first + m * period, ya);
+                if (pair) put(out + (channel + 1) * width, width, out_split, first + m * period, yb);
             }
-
-            put(out + channel * width, width, out_split, item, ya);
-            if (pair) put(out + (channel + 1) * width, width, out_split, item, yb);
         }
+    }
+
+    // the rest frame by frame, the last threads first (the first ones had one set more)
+    int const done = sets * span;
+
+    for (int item = done + kThreads - 1 - threadIdx.x; item < outputs; item += kThreads)
+    {
+        sinc_one<TAPS, CUBIC>(chain, phase_base, in, out, width, channels, out_split, first_output, item, in_origin, bank);
     }
 }
 
@@ -431,7 +570,7 @@ __device__ inline void run_half_band
 
 // ---- the cascade kernel -----------------------------------------------------
 
-__global__ __launch_bounds__(kThreads) void drb_cascade_kernel
+__global__ __launch_bounds__(kThreads, 6) void drb_cascade_kernel
     (
         Drb_Device_Chain const chain,
         Drb_Device_Call const * __restrict__ calls, int stream_count,
@@ -541,6 +680,7 @@ __global__ __launch_bounds__(kThreads) void drb_cascade_kernel
     if (ranges.fault) return;
 
     // -- load the source range -------------------------------------------------
+    if (!(chain.ablate & 8))
     {
         int const lo = ranges.lo[0], count = ranges.hi[0] - ranges.lo[0];
         int const shift = chain.delay_edge == 0 ? call.delay : 0;
@@ -584,7 +724,10 @@ __global__ __launch_bounds__(kThreads) void drb_cascade_kernel
         int const out_split = k + 1 < stages && chain.stages[k + 1].kind == kStageDown2x;
         float const * const kernel = table_at(stage.table);
 
-        if (stage.kind == kStageSinc)
+        if (chain.ablate & (stage.kind == kStageSinc ? 1 : stage.kind == kStageUp2x ? 2 : 4))
+        {
+        }
+        else if (stage.kind == kStageSinc)
         {
             if (stage.taps == 32 && !stage.cubic)
                 stage_sinc<32, 0>(chain, call.phase, in, out, width, channels, out_split, lo, hi - lo, ranges.lo[k], bank);
@@ -618,6 +761,7 @@ __global__ __launch_bounds__(kThreads) void drb_cascade_kernel
     }
 
     // -- store the tile ----------------------------------------------------------
+    if (!(chain.ablate & 16))
     {
         float const * const result = lds + (stages & 1) * buffer_floats;
         int const count = last - first;
@@ -1016,7 +1160,9 @@ int drb_hip_launch_cascade
         }
     }
 
-    size_t const dynamic = static_cast<size_t>(lds_bytes) + bank_floats * sizeof(float) + sizeof(Ranges);
+    // (DRB_AMD_EXACT_LDS_PAD=bytes: LDS asked for and not used, to time the kernel at fewer workgroups per CU)
+    static int const pad = [] { char const * const v = getenv("DRB_AMD_EXACT_LDS_PAD"); return v ? atoi(v) : 0; }();
+    size_t const dynamic = static_cast<size_t>(lds_bytes) + bank_floats * sizeof(float) + sizeof(Ranges) + pad;
 
     // (the attribute is per device and batches may live on several: set on every
     // launch that needs it, which is cheap, rather than remembered per process)
@@ -1039,9 +1185,20 @@ int drb_hip_launch_cascade
 
     unsigned const groups = static_cast<unsigned>((chain->channels + chain->channel_group - 1) / chain->channel_group);
 
+    // (DRB_AMD_SINC_SHARE=0: the fractional stage frame by frame throughout)
+    static bool const share = [] { char const * const v = getenv("DRB_AMD_SINC_SHARE"); return !(v && v[0] == '0'); }();
+    Drb_Device_Chain launched = *chain;
+
+    if (!share) launched.sinc_period = 0;
+
+    // (DRB_AMD_EXACT_ABLATE=mask: phases skipped, for timing only)
+    static int const ablate = [] { char const * const v = getenv("DRB_AMD_EXACT_ABLATE"); return v ? atoi(v) : 0; }();
+
+    launched.ablate = ablate;
+
     drb_cascade_kernel<<<dim3(static_cast<unsigned>(blocks), groups), dim3(kThreads), dynamic, static_cast<hipStream_t>(stream)>>>
     (
-        *chain, calls, stream_count, history,
+        launched, calls, stream_count, history,
         source_channel_stride, target_channel_stride, bank_floats, fault_flag
     );
 

@@ -9,6 +9,7 @@
 #include "drb_plan.h"
 #include "drb_hip.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 enum { layout_interleaved = 1, layout_planar = 2 };
@@ -565,10 +566,40 @@ void drb_plan_geometry (Drb_Plan const * plan, int lds_budget_bytes, Drb_Geometr
     geometry->history_frames = (int)((-lo + 4 + 3) / 4 * 4);
     if (geometry->history_frames < 4) geometry->history_frames = 4;
 
-    static int const tiles [] = { 2048, 1024, 512, 256, 128, 64, 32, 16, 8, 4 };
+    /* (2048 down to 16 in steps of 16 target frames, then halves) */
+    int tiles [140];
+    unsigned tile_count = 0;
 
-    /* The largest tile within the budget (which leaves room for a second workgroup
-     * on the CU), all channels in one workgroup.  Chains that decimate many
+    for (int t = 2048; t >= 16; t -= 16) tiles[tile_count++] = t;
+    for (int t = 8; t >= 4; t /= 2) tiles[tile_count++] = t;
+
+    {
+        /* (diagnostic: this tile or none, tools/exact_tiles.sh) */
+        char const * const forced = getenv("DRB_AMD_EXACT_TILE");
+
+        if (forced && atoi(forced) > 0)
+        {
+            tile_count = 0;
+            tiles[tile_count++] = atoi(forced);
+            lds_budget_bytes = drb_lds_hard_limit;
+        }
+    }
+
+    /* what the kernel keeps in LDS beside the two edge buffers: the fractional stage's
+     * bank, rows skewed by one float, and the index ranges */
+    int beside = 128;
+
+    for (int k = 0; k < plan->stage_count; k++)
+    {
+        if (plan->stages[k].kind == drb_stage_sinc)
+        {
+            beside += (plan->stages[k].arg >= 100 ? 32 : 64) * (plan->stages[k].arg % 100 + 1) * 4;
+        }
+    }
+
+    /* The largest tile within the budget (a third of a CU's LDS, less the allocation's
+     * granule: measured, three workgroups per CU run 1.2 to 1.4 times faster than two on
+     * a tile a fifth larger), all channels in one workgroup.  Chains that decimate many
      * channels a long way have none: their channels are dealt out to several
      * workgroups (half of them each, a quarter, one), and failing that a
      * workgroup takes its whole LDS. */
@@ -580,7 +611,7 @@ void drb_plan_geometry (Drb_Plan const * plan, int lds_budget_bytes, Drb_Geometr
         {
             int const group = (plan->channels + share - 1) / share;
 
-            for (unsigned t = 0; t < sizeof(tiles) / sizeof(tiles[0]); t++)
+            for (unsigned t = 0; t < tile_count; t++)
             {
                 if (pass == 0 && tiles[t] < 16) break;   /* (tiles that small are mostly look-back) */
 
@@ -601,7 +632,7 @@ void drb_plan_geometry (Drb_Plan const * plan, int lds_budget_bytes, Drb_Geometr
                 geometry->channel_group = group;
                 geometry->lds_bytes = (int)(2 * widest * group * 4);
 
-                if (geometry->lds_bytes <= limit) return;
+                if (geometry->lds_bytes + (pass == 0 ? beside : 0) <= limit) return;
             }
 
             if (group == 1) break;
