@@ -305,29 +305,65 @@ __device__ void stage_down2x
 // Row pick and blend: drb-audio-converter.c:881-941; linear blend 827-848;
 // Catmull-Rom 850-875.
 
-// where output `index` of the stage reads: its bank row, the position inside the row's
-// interval and the first input position (relative to the edge buffer's origin)
+// A position on the fractional stage's time line: whole input frames q and the rest r of
+// the accumulator, 0 <= r < source_delta (accumulator = q source_delta + r).
+struct Sinc_At
+{
+    long long q, r;
+};
+
+// the position of accumulator value `phase` (the floor division sinc_position makes)
+__device__ inline Sinc_At sinc_at (long long phase, long long sd, double scale)
+{
+    Sinc_At at;
+
+    at.q = static_cast<long long>(floor(static_cast<double>(phase) * scale));
+    at.r = phase - at.q * sd;
+
+    while (at.r < 0) { at.q -= 1; at.r += sd; }
+    while (at.r >= sd) { at.q += 1; at.r -= sd; }
+
+    return at;
+}
+
+// `by` further on (by.r < source_delta): whole numbers throughout, so a position reached in
+// steps is the position the division finds
+__device__ __forceinline__ void sinc_advance (Sinc_At & at, Sinc_At const & by, long long sd)
+{
+    at.q += by.q;
+    at.r += by.r;
+
+    if (at.r >= sd) { at.r -= sd; at.q += 1; }
+}
+
+// where the output at position `at` reads: its bank row, the position inside the row's
+// interval and the first input position (relative to the edge buffer's origin); the
+// phase conventions are sinc_position's
 template <int TAPS, int CUBIC>
 __device__ __forceinline__ void sinc_frame
     (
-        Drb_Device_Chain const & chain, long long phase_base, int index, int in_origin,
+        Drb_Device_Chain const & chain, Sinc_At const & at, int in_origin,
         int & row, float & sub, int & start
     )
 {
-    int consumed;
+    long long q = at.q, r = at.r;
     double blend;
 
-    sinc_position
-    (
-        phase_base + static_cast<long long>(index) * chain.target_delta,
-        chain.source_delta, chain.scale, chain.sinc_pull, consumed, blend
-    );
+    if (chain.sinc_pull)
+    {
+        blend = static_cast<double>(r) * chain.scale;
+    }
+    else
+    {
+        if (r == 0) { q -= 1; r = chain.source_delta; }
+        blend = static_cast<double>(r - 1) * chain.scale;
+    }
 
     double const scaled = blend * (CUBIC ? 29.0 : 63.0);
 
     row = static_cast<int>(scaled);
     sub = static_cast<float>(scaled - static_cast<double>(row));
-    start = consumed - TAPS - in_origin;
+    start = static_cast<int>(q) - TAPS - in_origin;
 }
 
 // the rows' sums of one frame and channel pair into the frame's two samples
@@ -383,13 +419,13 @@ __device__ __forceinline__ void sinc_blend (float2_t const * p, float sub, float
     }
 }
 
-// one output frame, all channels
+// one output frame (`item` of the stage's outputs, at position `at`), all channels
 template <int TAPS, int CUBIC>
 __device__ __forceinline__ void sinc_one
     (
-        Drb_Device_Chain const & chain, long long phase_base,
+        Drb_Device_Chain const & chain, Sinc_At const & at,
         float const * in, float * out, int width, int channels, int out_split,
-        int first_output, int item, int in_origin, float const * bank
+        int item, int in_origin, float const * bank
     )
 {
     // (p + x * k below must stay a rounded product and a rounded sum, as upstream's)
@@ -401,7 +437,7 @@ __device__ __forceinline__ void sinc_one
     int row, start;
     float sub;
 
-    sinc_frame<TAPS, CUBIC>(chain, phase_base, first_output + item, in_origin, row, sub, start);
+    sinc_frame<TAPS, CUBIC>(chain, at, in_origin, row, sub, start);
 
     float const * const rows = bank + row * kStride;
 
@@ -441,14 +477,14 @@ __device__ __forceinline__ void sinc_one
     }
 }
 
-// Outputs `period` apart sit at (nearly) the same fractional position: the rate ratio's
-// period, up to the slow drift of the fixed-point phase.  A work item takes kShare such
-// frames (item c of set q: frames c + period (kShare q + m)), and where all of them pick
-// the same bank row, as they do but for a frame in a million, every coefficient is read
-// from LDS once for the kShare frames: the stage is bound by its LDS reads, two thirds
-// of which were coefficients.  Each frame's sums are formed as sinc_one forms them.
-// Frames past the last full set, and any stage with fewer outputs than one set, go frame
-// by frame.
+// Outputs a whole number of the rate ratio's periods apart sit at (nearly) the same
+// fractional position: the same but for the slow drift of the fixed-point phase.  A work
+// item takes kShare such frames (item i: outputs i, i + part, ..., `part` a whole number
+// of periods), and where all of them pick the same bank row, as they do but for a frame
+// in a million, every coefficient is read from LDS once for the kShare frames.  Each
+// frame's sums are formed as sinc_one forms them.  What is left past kShare parts, and
+// any stage with fewer outputs than kShare periods, goes frame by frame.
+// A thread divides once (sinc_at) and steps from output to output in whole numbers.
 constexpr int kShare = 2;
 
 template <int TAPS, int CUBIC>
@@ -464,96 +500,110 @@ __device__ void stage_sinc
     constexpr int kRows = CUBIC ? 4 : 2;
     constexpr int kStride = TAPS + 1;
 
+    long long const sd = chain.source_delta;
     int const period = chain.sinc_period;
-    int const span = kShare * period;
-    int const sets = period > 0 ? outputs / span : 0;
+    int const part = period > 0 ? outputs / (kShare * period) * period : 0;
 
-    for (int item = threadIdx.x; item < sets * period; item += kThreads)
+    // a thread's next output but one, and a frame's partner
+    Sinc_At const stride = sinc_at(static_cast<long long>(kThreads) * chain.target_delta, sd, chain.scale);
+    Sinc_At const apart = sinc_at(static_cast<long long>(part) * chain.target_delta, sd, chain.scale);
+
+    if (static_cast<int>(threadIdx.x) < part)
     {
-        int const set = item / period, c = item - set * period;
-        int const first = c + set * span;
+        Sinc_At at = sinc_at(phase_base + static_cast<long long>(first_output + static_cast<int>(threadIdx.x)) * chain.target_delta, sd, chain.scale);
 
-        int row [kShare], start [kShare];
-        float sub [kShare];
-
-        #pragma unroll
-        for (int m = 0; m < kShare; m++)
+        for (int item = threadIdx.x; item < part; item += kThreads, sinc_advance(at, stride, sd))
         {
-            sinc_frame<TAPS, CUBIC>(chain, phase_base, first_output + first + m * period, in_origin, row[m], sub[m], start[m]);
-        }
+            Sinc_At frame [kShare];
+            int row [kShare], start [kShare];
+            float sub [kShare];
 
-        bool same = true;
-
-        #pragma unroll
-        for (int m = 1; m < kShare; m++) same = same && row[m] == row[0];
-
-        if (!same)
-        {
-            #pragma unroll 1
-            for (int m = 0; m < kShare; m++)
-            {
-                sinc_one<TAPS, CUBIC>(chain, phase_base, in, out, width, channels, out_split, first_output, first + m * period, in_origin, bank);
-            }
-
-            continue;
-        }
-
-        float const * const rows = bank + row[0] * kStride;
-
-        for (int channel = 0; channel < channels; channel += 2)
-        {
-            bool const pair = channel + 1 < channels;
-            float const * const a = in + channel * width;
-            float const * const b = pair ? a + width : a;
-
-            float2_t p [kShare][kRows];
+            frame[0] = at;
 
             #pragma unroll
-            for (int m = 0; m < kShare; m++)
+            for (int m = 1; m < kShare; m++) { frame[m] = frame[m - 1]; sinc_advance(frame[m], apart, sd); }
+
+            #pragma unroll
+            for (int m = 0; m < kShare; m++) sinc_frame<TAPS, CUBIC>(chain, frame[m], in_origin, row[m], sub[m], start[m]);
+
+            bool same = true;
+
+            #pragma unroll
+            for (int m = 1; m < kShare; m++) same = same && row[m] == row[0];
+
+            if (!same)
             {
                 #pragma unroll
-                for (int r = 0; r < kRows; r++) p[m][r] = float2_t{ 0.0f, 0.0f };
+                for (int m = 0; m < kShare; m++)
+                {
+                    sinc_one<TAPS, CUBIC>(chain, frame[m], in, out, width, channels, out_split, item + m * part, in_origin, bank);
+                }
+
+                continue;
             }
 
-            // (four taps at a time: unrolled further, the compiler starts every read of the
-            // stage at once and runs out of registers)
-            #pragma unroll 4
-            for (int t = 0; t < TAPS; t++)
-            {
-                float k [kRows];
+            float const * const rows = bank + row[0] * kStride;
 
-                #pragma unroll
-                for (int r = 0; r < kRows; r++) k[r] = rows[r * kStride + t];
+            for (int channel = 0; channel < channels; channel += 2)
+            {
+                bool const pair = channel + 1 < channels;
+                float const * const a = in + channel * width;
+                float const * const b = pair ? a + width : a;
+
+                float2_t p [kShare][kRows];
 
                 #pragma unroll
                 for (int m = 0; m < kShare; m++)
                 {
-                    float2_t const x = { a[start[m] + t], b[start[m] + t] };
+                    #pragma unroll
+                    for (int r = 0; r < kRows; r++) p[m][r] = float2_t{ 0.0f, 0.0f };
+                }
+
+                // (four taps at a time: unrolled further, the compiler starts every read of the
+                // stage at once and runs out of registers)
+                #pragma unroll 4
+                for (int t = 0; t < TAPS; t++)
+                {
+                    float k [kRows];
 
                     #pragma unroll
-                    for (int r = 0; r < kRows; r++) p[m][r] = p[m][r] + x * float2_t{ k[r], k[r] };
+                    for (int r = 0; r < kRows; r++) k[r] = rows[r * kStride + t];
+
+                    #pragma unroll
+                    for (int m = 0; m < kShare; m++)
+                    {
+                        float2_t const x = { a[start[m] + t], b[start[m] + t] };
+
+                        #pragma unroll
+                        for (int r = 0; r < kRows; r++) p[m][r] = p[m][r] + x * float2_t{ k[r], k[r] };
+                    }
                 }
-            }
 
-            #pragma unroll
-            for (int m = 0; m < kShare; m++)
-            {
-                float ya, yb;
+                #pragma unroll
+                for (int m = 0; m < kShare; m++)
+                {
+                    float ya, yb;
 
-                sinc_blend<CUBIC>(p[m], sub[m], ya, yb);
+                    sinc_blend<CUBIC>(p[m], sub[m], ya, yb);
 
-                put(out + channel * width, width, out_split, first + m * period, ya);
-                if (pair) put(out + (channel + 1) * width, width, out_split, first + m * period, yb);
+                    put(out + channel * width, width, out_split, item + m * part, ya);
+                    if (pair) put(out + (channel + 1) * width, width, out_split, item + m * part, yb);
+                }
             }
         }
     }
 
-    // the rest frame by frame, the last threads first (the first ones had one set more)
-    int const done = sets * span;
+    // the rest frame by frame, the last threads first (the first ones had one item more)
+    int const next = kShare * part + kThreads - 1 - static_cast<int>(threadIdx.x);
 
-    for (int item = done + kThreads - 1 - threadIdx.x; item < outputs; item += kThreads)
+    if (next < outputs)
     {
-        sinc_one<TAPS, CUBIC>(chain, phase_base, in, out, width, channels, out_split, first_output, item, in_origin, bank);
+        Sinc_At at = sinc_at(phase_base + static_cast<long long>(first_output + next) * chain.target_delta, sd, chain.scale);
+
+        for (int item = next; item < outputs; item += kThreads, sinc_advance(at, stride, sd))
+        {
+            sinc_one<TAPS, CUBIC>(chain, at, in, out, width, channels, out_split, item, in_origin, bank);
+        }
     }
 }
 
