@@ -41,7 +41,9 @@ typedef struct Drb_Device_Chain
                                 recurs (but for the fixed-point drift); 0: unknown */
     int ablate;              /* diagnostic: bit mask of phases to skip (timing only):
                                 1 fractional stage, 2 up-samplers, 4 down-samplers,
-                                8 source loads, 16 target stores                  */
+                                8 source loads, 16 target stores; 32 (tests): the
+                                fractional stage's pairs of frames all take the way
+                                of pairs that differ in their bank row            */
     Drb_Device_Stage stages [drb_device_max_stages];
 }
 Drb_Device_Chain;

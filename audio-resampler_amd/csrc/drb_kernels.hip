@@ -526,7 +526,8 @@ __device__ void stage_sinc
             #pragma unroll
             for (int m = 0; m < kShare; m++) sinc_frame<TAPS, CUBIC>(chain, frame[m], in_origin, row[m], sub[m], start[m]);
 
-            bool same = true;
+            // (ablate bit 32, a test's: every item takes the way of frames whose rows differ)
+            bool same = !(chain.ablate & 32);
 
             #pragma unroll
             for (int m = 1; m < kShare; m++) same = same && row[m] == row[0];
@@ -1235,16 +1236,18 @@ int drb_hip_launch_cascade
 
     unsigned const groups = static_cast<unsigned>((chain->channels + chain->channel_group - 1) / chain->channel_group);
 
-    // (DRB_AMD_SINC_SHARE=0: the fractional stage frame by frame throughout)
-    static bool const share = [] { char const * const v = getenv("DRB_AMD_SINC_SHARE"); return !(v && v[0] == '0'); }();
+    // (DRB_AMD_SINC_SHARE=0: the fractional stage frame by frame throughout; =2: frames taken
+    // two at a time, every pair the way of pairs whose bank rows differ, which else one pair
+    // in a million takes: for the tests)
+    static int const share = [] { char const * const v = getenv("DRB_AMD_SINC_SHARE"); return v ? atoi(v) : 1; }();
     Drb_Device_Chain launched = *chain;
 
-    if (!share) launched.sinc_period = 0;
+    if (share == 0) launched.sinc_period = 0;
 
     // (DRB_AMD_EXACT_ABLATE=mask: phases skipped, for timing only)
     static int const ablate = [] { char const * const v = getenv("DRB_AMD_EXACT_ABLATE"); return v ? atoi(v) : 0; }();
 
-    launched.ablate = ablate;
+    launched.ablate = (ablate & 31) | (share == 2 ? 32 : 0);
 
     drb_cascade_kernel<<<dim3(static_cast<unsigned>(blocks), groups), dim3(kThreads), dynamic, static_cast<hipStream_t>(stream)>>>
     (
