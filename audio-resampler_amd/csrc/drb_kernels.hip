@@ -43,15 +43,18 @@ __device__ inline float const * table_at (int float_offset)
     return reinterpret_cast<float const *>(drb_table_words) + float_offset;
 }
 
-// One rounding per operation: the scalar helpers below say so by construction
-// (__fmul_rn / __fadd_rn), whatever the contraction flags; the packed two-channel
-// arithmetic of the fractional stage is plain vector code, kept from being
-// fused by the pragma in front of it (and by -ffp-contract=off in the Makefile).
+// One rounding per operation, whatever the command line says about contraction: from
+// here to the end of the file no product is fused with a sum (the pragma takes the
+// `contract` flag off every operation compiled below it, the helpers' included; the
+// Makefile passes -ffp-contract=off as well).  The packed two-channel arithmetic of the
+// fractional stage is plain vector code under the same rule.
+#pragma clang fp contract(off)
+
 typedef float float2_t __attribute__((ext_vector_type(2)));
 
-__device__ inline float mul (float a, float b) { return __fmul_rn(a, b); }
-__device__ inline float add (float a, float b) { return __fadd_rn(a, b); }
-__device__ inline float mac (float acc, float a, float b) { return __fadd_rn(acc, __fmul_rn(a, b)); }
+__device__ inline float mul (float a, float b) { return a * b; }
+__device__ inline float add (float a, float b) { return a + b; }
+__device__ inline float mac (float acc, float a, float b) { float const product = a * b; return acc + product; }
 
 __device__ inline int floor_half (int v) { return v >> 1; }
 
