@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <type_traits>
 #include <cstdlib>
 #include <mutex>
 
@@ -191,7 +192,7 @@ struct Ranges
 // x[first_frame - N + 1].  Each work item produces four consecutive source
 // frames' worth of output for one channel from one aligned window in registers.
 template <int N>
-__device__ void stage_up2x
+__device__ __forceinline__ void stage_up2x
     (
         float const * in, float * out, int width, int channels, int out_split,
         int frames, int out_offset, float const * kernel
@@ -245,7 +246,7 @@ __device__ void stage_up2x
 // is x[2 first_frame - 2N + 1]; the taps therefore sit in plane 0 and the
 // centre sample in plane 1.
 template <int N>
-__device__ void stage_down2x
+__device__ __forceinline__ void stage_down2x
     (
         float const * in, float * out, int width, int channels, int out_split,
         int frames, float const * kernel
@@ -370,7 +371,8 @@ __device__ __forceinline__ void sinc_frame
 }
 
 // the rows' sums of one frame and channel pair into the frame's two samples
-template <int CUBIC>
+// (PAIR false: the sums' first halves only, a lone channel's)
+template <int CUBIC, bool PAIR = true>
 __device__ __forceinline__ void sinc_blend (float2_t const * p, float sub, float & ya, float & yb)
 {
     constexpr int kRows = CUBIC ? 4 : 2;
@@ -400,7 +402,7 @@ __device__ __forceinline__ void sinc_blend (float2_t const * p, float sub, float
             for (int j = 0; j < 4; j++)
             {
                 sa = mac(sa, m[i][j], pa[j]);
-                sb = mac(sb, m[i][j], pb[j]);
+                if (PAIR) sb = mac(sb, m[i][j], pb[j]);
             }
 
             ca[i] = sa;
@@ -408,22 +410,30 @@ __device__ __forceinline__ void sinc_blend (float2_t const * p, float sub, float
         }
 
         ya = add(mul(add(mul(add(mul(ca[3], sub), ca[2]), sub), ca[1]), sub), ca[0]);
-        yb = add(mul(add(mul(add(mul(cb[3], sub), cb[2]), sub), cb[1]), sub), cb[0]);
+        yb = PAIR ? add(mul(add(mul(add(mul(cb[3], sub), cb[2]), sub), cb[1]), sub), cb[0]) : ya;
     }
     else
     {
         float const a0 = mac(mac(0.0f, 1.0f, pa[0]), 0.0f, pa[1]);
         float const a1 = mac(mac(0.0f, -1.0f, pa[0]), 1.0f, pa[1]);
-        float const b0 = mac(mac(0.0f, 1.0f, pb[0]), 0.0f, pb[1]);
-        float const b1 = mac(mac(0.0f, -1.0f, pb[0]), 1.0f, pb[1]);
-
         ya = add(mul(a1, sub), a0);
-        yb = add(mul(b1, sub), b0);
+
+        if (PAIR)
+        {
+            float const b0 = mac(mac(0.0f, 1.0f, pb[0]), 0.0f, pb[1]);
+            float const b1 = mac(mac(0.0f, -1.0f, pb[0]), 1.0f, pb[1]);
+
+            yb = add(mul(b1, sub), b0);
+        }
+        else yb = ya;
     }
 }
 
 // one output frame (`item` of the stage's outputs, at position `at`), all channels
-template <int TAPS, int CUBIC>
+// (LONE: the workgroup's channel count may be odd, and its last channel then goes alone, in
+// scalar registers: a packed instruction with one half idle would issue at half the rate
+// for nothing.  The kernel image without LONE is the one for even counts.)
+template <int TAPS, int CUBIC, bool LONE>
 __device__ __forceinline__ void sinc_one
     (
         Drb_Device_Chain const & chain, Sinc_At const & at,
@@ -444,39 +454,98 @@ __device__ __forceinline__ void sinc_one
 
     float const * const rows = bank + row * kStride;
 
-    for (int channel = 0; channel < channels; channel += 2)
+    if constexpr (!LONE)
     {
-        bool const pair = channel + 1 < channels;
-        float const * const a = in + channel * width + start;
-        float const * const b = pair ? a + width : a;
-
-        // Two channels side by side in packed registers: one v_pk_mul_f32 and one
-        // v_pk_add_f32 per tap and row, each half rounded as the scalar
-        // instructions round, in the same order.
-        float2_t p [kRows];
-
-        #pragma unroll
-        for (int r = 0; r < kRows; r++) p[r] = float2_t{ 0.0f, 0.0f };
-
-        #pragma unroll
-        for (int t = 0; t < TAPS; t++)
+        for (int channel = 0; channel < channels; channel += 2)
         {
-            float2_t const x = { a[t], b[t] };
+            bool const pair = channel + 1 < channels;
+            float const * const a = in + channel * width + start;
+            float const * const b = pair ? a + width : a;
+
+            // Two channels side by side in packed registers: one v_pk_mul_f32 and one
+            // v_pk_add_f32 per tap and row, each half rounded as the scalar
+            // instructions round, in the same order.
+            float2_t p [kRows];
+
+            #pragma unroll
+            for (int r = 0; r < kRows; r++) p[r] = float2_t{ 0.0f, 0.0f };
+
+            #pragma unroll
+            for (int t = 0; t < TAPS; t++)
+            {
+                float2_t const x = { a[t], b[t] };
+
+                #pragma unroll
+                for (int r = 0; r < kRows; r++)
+                {
+                    float const k = rows[r * kStride + t];
+                    p[r] = p[r] + x * float2_t{ k, k };
+                }
+            }
+
+            float ya, yb;
+
+            sinc_blend<CUBIC>(p, sub, ya, yb);
+
+            put(out + channel * width, width, out_split, item, ya);
+            if (pair) put(out + (channel + 1) * width, width, out_split, item, yb);
+        }
+    }
+    else
+    {
+        // Two channels side by side in packed registers: one v_pk_mul_f32 and one
+        // v_pk_add_f32 per tap and row, each half rounded as the scalar instructions
+        // round, in the same order.  A lone channel (the last of an odd count) in scalar
+        // registers: a packed instruction with one half idle would issue at half the rate
+        // for nothing.
+        auto channels_at = [&] (int channel, auto paired) __attribute__((always_inline))
+        {
+            constexpr bool kPair = decltype(paired)::value;
+            typedef typename std::conditional<kPair, float2_t, float>::type sums_t;
+
+            float const * const a = in + channel * width + start;
+            float const * const b = a + width;
+
+            sums_t p [kRows];
+
+            #pragma unroll
+            for (int r = 0; r < kRows; r++) p[r] = sums_t{};
+
+            #pragma unroll
+            for (int t = 0; t < TAPS; t++)
+            {
+                #pragma unroll
+                for (int r = 0; r < kRows; r++)
+                {
+                    float const k = rows[r * kStride + t];
+
+                    if constexpr (kPair) p[r] = p[r] + float2_t{ a[t], b[t] } * float2_t{ k, k };
+                    else p[r] = p[r] + a[t] * k;
+                }
+            }
+
+            float2_t both [kRows];
 
             #pragma unroll
             for (int r = 0; r < kRows; r++)
             {
-                float const k = rows[r * kStride + t];
-                p[r] = p[r] + x * float2_t{ k, k };
+                if constexpr (kPair) both[r] = p[r];
+                else both[r] = float2_t{ p[r], p[r] };
             }
+
+            float ya, yb;
+
+            sinc_blend<CUBIC, kPair>(both, sub, ya, yb);
+
+            put(out + channel * width, width, out_split, item, ya);
+            if (kPair) put(out + (channel + 1) * width, width, out_split, item, yb);
+        };
+
+        for (int channel = 0; channel < channels; channel += 2)
+        {
+            if (channel + 1 < channels) channels_at(channel, std::true_type{});
+            else channels_at(channel, std::false_type{});
         }
-
-        float ya, yb;
-
-        sinc_blend<CUBIC>(p, sub, ya, yb);
-
-        put(out + channel * width, width, out_split, item, ya);
-        if (pair) put(out + (channel + 1) * width, width, out_split, item, yb);
     }
 }
 
@@ -490,8 +559,8 @@ __device__ __forceinline__ void sinc_one
 // A thread divides once (sinc_at) and steps from output to output in whole numbers.
 constexpr int kShare = 2;
 
-template <int TAPS, int CUBIC>
-__device__ void stage_sinc
+template <int TAPS, int CUBIC, bool LONE>
+__device__ __forceinline__ void stage_sinc
     (
         Drb_Device_Chain const & chain, long long phase_base,
         float const * in, float * out, int width, int channels, int out_split,
@@ -540,7 +609,7 @@ __device__ void stage_sinc
                 #pragma unroll
                 for (int m = 0; m < kShare; m++)
                 {
-                    sinc_one<TAPS, CUBIC>(chain, frame[m], in, out, width, channels, out_split, item + m * part, in_origin, bank);
+                    sinc_one<TAPS, CUBIC, LONE>(chain, frame[m], in, out, width, channels, out_split, item + m * part, in_origin, bank);
                 }
 
                 continue;
@@ -548,50 +617,121 @@ __device__ void stage_sinc
 
             float const * const rows = bank + row[0] * kStride;
 
-            for (int channel = 0; channel < channels; channel += 2)
+            if constexpr (!LONE)
             {
-                bool const pair = channel + 1 < channels;
-                float const * const a = in + channel * width;
-                float const * const b = pair ? a + width : a;
-
-                float2_t p [kShare][kRows];
-
-                #pragma unroll
-                for (int m = 0; m < kShare; m++)
+                for (int channel = 0; channel < channels; channel += 2)
                 {
-                    #pragma unroll
-                    for (int r = 0; r < kRows; r++) p[m][r] = float2_t{ 0.0f, 0.0f };
-                }
+                    bool const pair = channel + 1 < channels;
+                    float const * const a = in + channel * width;
+                    float const * const b = pair ? a + width : a;
 
-                // (four taps at a time: unrolled further, the compiler starts every read of the
-                // stage at once and runs out of registers)
-                #pragma unroll 4
-                for (int t = 0; t < TAPS; t++)
-                {
-                    float k [kRows];
-
-                    #pragma unroll
-                    for (int r = 0; r < kRows; r++) k[r] = rows[r * kStride + t];
+                    float2_t p [kShare][kRows];
 
                     #pragma unroll
                     for (int m = 0; m < kShare; m++)
                     {
-                        float2_t const x = { a[start[m] + t], b[start[m] + t] };
+                        #pragma unroll
+                        for (int r = 0; r < kRows; r++) p[m][r] = float2_t{ 0.0f, 0.0f };
+                    }
+
+                    // (four taps at a time: unrolled further, the compiler starts every read of the
+                    // stage at once and runs out of registers)
+                    #pragma unroll 4
+                    for (int t = 0; t < TAPS; t++)
+                    {
+                        float k [kRows];
 
                         #pragma unroll
-                        for (int r = 0; r < kRows; r++) p[m][r] = p[m][r] + x * float2_t{ k[r], k[r] };
+                        for (int r = 0; r < kRows; r++) k[r] = rows[r * kStride + t];
+
+                        #pragma unroll
+                        for (int m = 0; m < kShare; m++)
+                        {
+                            float2_t const x = { a[start[m] + t], b[start[m] + t] };
+
+                            #pragma unroll
+                            for (int r = 0; r < kRows; r++) p[m][r] = p[m][r] + x * float2_t{ k[r], k[r] };
+                        }
+                    }
+
+                    #pragma unroll
+                    for (int m = 0; m < kShare; m++)
+                    {
+                        float ya, yb;
+
+                        sinc_blend<CUBIC>(p[m], sub[m], ya, yb);
+
+                        put(out + channel * width, width, out_split, item + m * part, ya);
+                        if (pair) put(out + (channel + 1) * width, width, out_split, item + m * part, yb);
                     }
                 }
-
-                #pragma unroll
-                for (int m = 0; m < kShare; m++)
+            }
+            else
+            {
+                auto channels_at = [&] (int channel, auto paired) __attribute__((always_inline))
                 {
-                    float ya, yb;
+                    constexpr bool kPair = decltype(paired)::value;
+                    typedef typename std::conditional<kPair, float2_t, float>::type sums_t;
 
-                    sinc_blend<CUBIC>(p[m], sub[m], ya, yb);
+                    float const * const a = in + channel * width;
+                    float const * const b = a + width;
 
-                    put(out + channel * width, width, out_split, item + m * part, ya);
-                    if (pair) put(out + (channel + 1) * width, width, out_split, item + m * part, yb);
+                    sums_t p [kShare][kRows];
+
+                    #pragma unroll
+                    for (int m = 0; m < kShare; m++)
+                    {
+                        #pragma unroll
+                        for (int r = 0; r < kRows; r++) p[m][r] = sums_t{};
+                    }
+
+                    // (four taps at a time: unrolled further, the compiler starts every read of the
+                    // stage at once and runs out of registers)
+                    #pragma unroll 4
+                    for (int t = 0; t < TAPS; t++)
+                    {
+                        float k [kRows];
+
+                        #pragma unroll
+                        for (int r = 0; r < kRows; r++) k[r] = rows[r * kStride + t];
+
+                        #pragma unroll
+                        for (int m = 0; m < kShare; m++)
+                        {
+                            #pragma unroll
+                            for (int r = 0; r < kRows; r++)
+                            {
+                                if constexpr (kPair) p[m][r] = p[m][r] + float2_t{ a[start[m] + t], b[start[m] + t] } * float2_t{ k[r], k[r] };
+                                else p[m][r] = p[m][r] + a[start[m] + t] * k[r];
+                            }
+                        }
+                    }
+
+                    #pragma unroll
+                    for (int m = 0; m < kShare; m++)
+                    {
+                        float2_t both [kRows];
+
+                        #pragma unroll
+                        for (int r = 0; r < kRows; r++)
+                        {
+                            if constexpr (kPair) both[r] = p[m][r];
+                            else both[r] = float2_t{ p[m][r], p[m][r] };
+                        }
+
+                        float ya, yb;
+
+                        sinc_blend<CUBIC, kPair>(both, sub[m], ya, yb);
+
+                        put(out + channel * width, width, out_split, item + m * part, ya);
+                        if (kPair) put(out + (channel + 1) * width, width, out_split, item + m * part, yb);
+                    }
+                };
+
+                for (int channel = 0; channel < channels; channel += 2)
+                {
+                    if (channel + 1 < channels) channels_at(channel, std::true_type{});
+                    else channels_at(channel, std::false_type{});
                 }
             }
         }
@@ -606,13 +746,13 @@ __device__ void stage_sinc
 
         for (int item = next; item < outputs; item += kThreads, sinc_advance(at, stride, sd))
         {
-            sinc_one<TAPS, CUBIC>(chain, at, in, out, width, channels, out_split, item, in_origin, bank);
+            sinc_one<TAPS, CUBIC, LONE>(chain, at, in, out, width, channels, out_split, item, in_origin, bank);
         }
     }
 }
 
 template <int N>
-__device__ inline void run_half_band
+__device__ __forceinline__ void run_half_band
     (
         int kind, float const * in, float * out, int width, int channels, int out_split,
         int frames, int out_offset, float const * kernel
@@ -624,6 +764,7 @@ __device__ inline void run_half_band
 
 // ---- the cascade kernel -----------------------------------------------------
 
+template <bool LONE>
 __global__ __launch_bounds__(kThreads, 6) void drb_cascade_kernel
     (
         Drb_Device_Chain const chain,
@@ -784,13 +925,13 @@ __global__ __launch_bounds__(kThreads, 6) void drb_cascade_kernel
         else if (stage.kind == kStageSinc)
         {
             if (stage.taps == 32 && !stage.cubic)
-                stage_sinc<32, 0>(chain, call.phase, in, out, width, channels, out_split, lo, hi - lo, ranges.lo[k], bank);
+                stage_sinc<32, 0, LONE>(chain, call.phase, in, out, width, channels, out_split, lo, hi - lo, ranges.lo[k], bank);
             else if (stage.taps == 32)
-                stage_sinc<32, 1>(chain, call.phase, in, out, width, channels, out_split, lo, hi - lo, ranges.lo[k], bank);
+                stage_sinc<32, 1, LONE>(chain, call.phase, in, out, width, channels, out_split, lo, hi - lo, ranges.lo[k], bank);
             else if (!stage.cubic)
-                stage_sinc<16, 0>(chain, call.phase, in, out, width, channels, out_split, lo, hi - lo, ranges.lo[k], bank);
+                stage_sinc<16, 0, LONE>(chain, call.phase, in, out, width, channels, out_split, lo, hi - lo, ranges.lo[k], bank);
             else
-                stage_sinc<16, 1>(chain, call.phase, in, out, width, channels, out_split, lo, hi - lo, ranges.lo[k], bank);
+                stage_sinc<16, 1, LONE>(chain, call.phase, in, out, width, channels, out_split, lo, hi - lo, ranges.lo[k], bank);
         }
         else
         {
@@ -1220,11 +1361,17 @@ int drb_hip_launch_cascade
 
     // (the attribute is per device and batches may live on several: set on every
     // launch that needs it, which is cheap, rather than remembered per process)
+    // the image whose fractional stage takes a lone channel in scalar registers, where a
+    // workgroup's channel count can be odd (DRB_AMD_EXACT_LONE=0: the packed image throughout)
+    static bool const lone_allowed = [] { char const * const v = getenv("DRB_AMD_EXACT_LONE"); return !(v && v[0] == '0'); }();
+    bool const lone = lone_allowed && chain->channel_group >= 1
+                   && (chain->channel_group % 2 != 0 || (chain->channels % chain->channel_group) % 2 != 0);
+
     if (dynamic > 48 * 1024)
     {
         hipError_t const status = hipFuncSetAttribute
         (
-            reinterpret_cast<void const *>(drb_cascade_kernel),
+            lone ? reinterpret_cast<void const *>(drb_cascade_kernel<true>) : reinterpret_cast<void const *>(drb_cascade_kernel<false>),
             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(dynamic)
         );
 
@@ -1252,11 +1399,22 @@ int drb_hip_launch_cascade
 
     launched.ablate = (ablate & 31) | (share == 2 ? 32 : 0);
 
-    drb_cascade_kernel<<<dim3(static_cast<unsigned>(blocks), groups), dim3(kThreads), dynamic, static_cast<hipStream_t>(stream)>>>
-    (
-        launched, calls, stream_count, history,
-        source_channel_stride, target_channel_stride, bank_floats, fault_flag
-    );
+    if (lone)
+    {
+        drb_cascade_kernel<true><<<dim3(static_cast<unsigned>(blocks), groups), dim3(kThreads), dynamic, static_cast<hipStream_t>(stream)>>>
+        (
+            launched, calls, stream_count, history,
+            source_channel_stride, target_channel_stride, bank_floats, fault_flag
+        );
+    }
+    else
+    {
+        drb_cascade_kernel<false><<<dim3(static_cast<unsigned>(blocks), groups), dim3(kThreads), dynamic, static_cast<hipStream_t>(stream)>>>
+        (
+            launched, calls, stream_count, history,
+            source_channel_stride, target_channel_stride, bank_floats, fault_flag
+        );
+    }
 
     return hipGetLastError();
 }
