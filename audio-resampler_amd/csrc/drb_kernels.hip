@@ -432,8 +432,8 @@ __device__ __forceinline__ void sinc_blend (float2_t const * p, float sub, float
 // one output frame (`item` of the stage's outputs, at position `at`), all channels
 // (LONE: the workgroup's channel count may be odd, and its last channel then goes alone, in
 // scalar registers: a packed instruction with one half idle would issue at half the rate
-// for nothing.  The kernel image without LONE is the one for even counts.)
-template <int TAPS, int CUBIC, bool LONE>
+// for nothing.  LONE 0: the image for even counts; 1: odd counts; 2: one channel a workgroup.)
+template <int TAPS, int CUBIC, int LONE>
 __device__ __forceinline__ void sinc_one
     (
         Drb_Device_Chain const & chain, Sinc_At const & at,
@@ -541,10 +541,17 @@ __device__ __forceinline__ void sinc_one
             if (kPair) put(out + (channel + 1) * width, width, out_split, item, yb);
         };
 
-        for (int channel = 0; channel < channels; channel += 2)
+        if constexpr (LONE == 2)
         {
-            if (channel + 1 < channels) channels_at(channel, std::true_type{});
-            else channels_at(channel, std::false_type{});
+            channels_at(0, std::false_type{});
+        }
+        else
+        {
+            for (int channel = 0; channel < channels; channel += 2)
+            {
+                if (channel + 1 < channels) channels_at(channel, std::true_type{});
+                else channels_at(channel, std::false_type{});
+            }
         }
     }
 }
@@ -559,7 +566,7 @@ __device__ __forceinline__ void sinc_one
 // A thread divides once (sinc_at) and steps from output to output in whole numbers.
 constexpr int kShare = 2;
 
-template <int TAPS, int CUBIC, bool LONE>
+template <int TAPS, int CUBIC, int LONE>
 __device__ __forceinline__ void stage_sinc
     (
         Drb_Device_Chain const & chain, long long phase_base,
@@ -728,10 +735,17 @@ __device__ __forceinline__ void stage_sinc
                     }
                 };
 
-                for (int channel = 0; channel < channels; channel += 2)
+                if constexpr (LONE == 2)
                 {
-                    if (channel + 1 < channels) channels_at(channel, std::true_type{});
-                    else channels_at(channel, std::false_type{});
+                    channels_at(0, std::false_type{});
+                }
+                else
+                {
+                    for (int channel = 0; channel < channels; channel += 2)
+                    {
+                        if (channel + 1 < channels) channels_at(channel, std::true_type{});
+                        else channels_at(channel, std::false_type{});
+                    }
                 }
             }
         }
@@ -764,7 +778,7 @@ __device__ __forceinline__ void run_half_band
 
 // ---- the cascade kernel -----------------------------------------------------
 
-template <bool LONE>
+template <int LONE>
 __global__ __launch_bounds__(kThreads, 6) void drb_cascade_kernel
     (
         Drb_Device_Chain const chain,
@@ -1364,14 +1378,16 @@ int drb_hip_launch_cascade
     // the image whose fractional stage takes a lone channel in scalar registers, where a
     // workgroup's channel count can be odd (DRB_AMD_EXACT_LONE=0: the packed image throughout)
     static bool const lone_allowed = [] { char const * const v = getenv("DRB_AMD_EXACT_LONE"); return !(v && v[0] == '0'); }();
-    bool const lone = lone_allowed && chain->channel_group >= 1
-                   && (chain->channel_group % 2 != 0 || (chain->channels % chain->channel_group) % 2 != 0);
+    bool const odd = lone_allowed && chain->channel_group >= 1
+                  && (chain->channel_group % 2 != 0 || (chain->channels % chain->channel_group) % 2 != 0);
+    int const lone = !odd ? 0 : chain->channel_group == 1 ? 2 : 1;
 
     if (dynamic > 48 * 1024)
     {
         hipError_t const status = hipFuncSetAttribute
         (
-            lone ? reinterpret_cast<void const *>(drb_cascade_kernel<true>) : reinterpret_cast<void const *>(drb_cascade_kernel<false>),
+            lone == 2 ? reinterpret_cast<void const *>(drb_cascade_kernel<2>)
+                      : lone ? reinterpret_cast<void const *>(drb_cascade_kernel<1>) : reinterpret_cast<void const *>(drb_cascade_kernel<0>),
             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(dynamic)
         );
 
@@ -1399,9 +1415,17 @@ int drb_hip_launch_cascade
 
     launched.ablate = (ablate & 31) | (share == 2 ? 32 : 0);
 
-    if (lone)
+    if (lone == 2)
     {
-        drb_cascade_kernel<true><<<dim3(static_cast<unsigned>(blocks), groups), dim3(kThreads), dynamic, static_cast<hipStream_t>(stream)>>>
+        drb_cascade_kernel<2><<<dim3(static_cast<unsigned>(blocks), groups), dim3(kThreads), dynamic, static_cast<hipStream_t>(stream)>>>
+        (
+            launched, calls, stream_count, history,
+            source_channel_stride, target_channel_stride, bank_floats, fault_flag
+        );
+    }
+    else if (lone)
+    {
+        drb_cascade_kernel<1><<<dim3(static_cast<unsigned>(blocks), groups), dim3(kThreads), dynamic, static_cast<hipStream_t>(stream)>>>
         (
             launched, calls, stream_count, history,
             source_channel_stride, target_channel_stride, bank_floats, fault_flag
@@ -1409,7 +1433,7 @@ int drb_hip_launch_cascade
     }
     else
     {
-        drb_cascade_kernel<false><<<dim3(static_cast<unsigned>(blocks), groups), dim3(kThreads), dynamic, static_cast<hipStream_t>(stream)>>>
+        drb_cascade_kernel<0><<<dim3(static_cast<unsigned>(blocks), groups), dim3(kThreads), dynamic, static_cast<hipStream_t>(stream)>>>
         (
             launched, calls, stream_count, history,
             source_channel_stride, target_channel_stride, bank_floats, fault_flag
