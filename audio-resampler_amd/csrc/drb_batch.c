@@ -272,6 +272,21 @@ static void build_chain (DrbAmd_Batch_Config const * config, Drb_Plan const * pl
     }
 }
 
+/* one channel per workgroup of the exact kernel: chains without a fractional stage (its
+ * position and coefficients are what channels share) in planar buffers (a workgroup that
+ * takes one channel of interleaved frames reads every frame for a fraction of it) */
+static int channels_apart (DrbAmd_Batch_Config const * config, Drb_Plan const * plan)
+{
+    if (config->layout != drb_amd_layout_planar || plan->channels < 2) return 0;
+
+    for (int k = 0; k < plan->stage_count; k++)
+    {
+        if (plan->stages[k].kind == drb_stage_sinc) return 0;
+    }
+
+    return 1;
+}
+
 enum { lds_budget = 53500, fast_lds_budget = 78 * 1024, split_lds_budget = 160 * 1024 };
 
 static DrbAmd_Status resolve (DrbAmd_Batch_Config const * config, Drb_Plan * plan)
@@ -293,7 +308,7 @@ static DrbAmd_Status resolve (DrbAmd_Batch_Config const * config, Drb_Plan * pla
     {
         Drb_Geometry geometry;
 
-        drb_plan_geometry(plan, lds_budget, &geometry);
+        drb_plan_geometry(plan, lds_budget, channels_apart(config, plan), &geometry);
 
         if (geometry.lds_bytes > drb_lds_hard_limit)
         {
@@ -544,7 +559,7 @@ static int make_launches (DrbAmd_Batch_Config const * config, Drb_Plan const * p
             if (!launch->doubles && !launch->halves) return no_launches("launch %d of %d: a slicer alone", i + 1, count);   /* re-blocking, no filter */
         }
 
-        drb_plan_geometry(&part, lds_budget, &geometry);
+        drb_plan_geometry(&part, lds_budget, 0, &geometry);
         drb_plan_fast_geometry(&part, fast_lds_budget, &launch->fast);
 
         /* buffers between launches are planar float32 */
@@ -658,7 +673,7 @@ DrbAmd_Status drb_amd_plan_info (DrbAmd_Batch_Config const * config, DrbAmd_Plan
 
     if (status != drb_amd_ok) return status;
 
-    drb_plan_geometry(&plan, lds_budget, &geometry);
+    drb_plan_geometry(&plan, lds_budget, channels_apart(config, &plan), &geometry);
 
     memset(info, 0, sizeof(*info));
 
@@ -860,7 +875,7 @@ DrbAmd_Status drb_amd_batch_create (DrbAmd_Batch_Config const * config, DrbAmd_B
     batch->last_slot = -1;
     batch->sample_bytes = config->sample_type == drb_amd_sample_i16 ? 2 : 4;
 
-    drb_plan_geometry(&plan, lds_budget, &batch->geometry);
+    drb_plan_geometry(&plan, lds_budget, channels_apart(config, &plan), &batch->geometry);
     build_chain(config, &plan, &batch->geometry, &batch->chain);
 
     batch->launch_count = build_launches(config, &plan, batch->launches);

@@ -554,7 +554,7 @@ static long long input_width (Drb_Plan const * plan, Drb_Stage const * stage, lo
     return width;
 }
 
-void drb_plan_geometry (Drb_Plan const * plan, int lds_budget_bytes, Drb_Geometry * geometry)
+void drb_plan_geometry (Drb_Plan const * plan, int lds_budget_bytes, int channels_apart, Drb_Geometry * geometry)
 {
     long long lo = 0;
 
@@ -610,6 +610,8 @@ void drb_plan_geometry (Drb_Plan const * plan, int lds_budget_bytes, Drb_Geometr
         for (int share = 1; share <= 8; share *= 2)
         {
             int const group = (plan->channels + share - 1) / share;
+
+            if (pass == 0 && channels_apart && group > 1) continue;
 
             for (unsigned t = 0; t < tile_count; t++)
             {

@@ -132,7 +132,10 @@ Drb_Geometry;
 enum { drb_lds_hard_limit = 148 * 1024 };
 
 /* geometry->lds_bytes is above drb_lds_hard_limit where no tile fits: such a plan does not run */
-void drb_plan_geometry (Drb_Plan const * plan, int lds_budget_bytes, Drb_Geometry * geometry);
+/* channels_apart: one channel per workgroup where a tile fits that way (chains of half-band
+ * stages only, whose channels have nothing in common, in planar buffers: the tile grows
+ * and less look-back is recomputed; measured 6 % on 8 channels 96 -> 48 kHz) */
+void drb_plan_geometry (Drb_Plan const * plan, int lds_budget_bytes, int channels_apart, Drb_Geometry * geometry);
 
 struct Drb_Fast_Chain;
 
